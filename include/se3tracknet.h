@@ -1,0 +1,142 @@
+/* se3tracknet.h -- C ABI of the MI355X (gfx950) se(3)-TrackNet per-frame inference hot path.
+ *
+ * The reference (wenbowen123/iros20-6d-pose-tracking) has no FFI: its boundary is the Python
+ * class predict.py:127 `Tracker` plus three file formats.  Every entry point below replaces one
+ * reference call site on the path `Tracker.on_track` (predict.py:217-296); the Python mirror in
+ * iros20-6d-pose-tracking_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *   - plain C types only; device pointers are caller-owned (e.g. torch tensors' data_ptr());
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - every se3tn_* compute call is stream-ordered and asynchronous: no hidden hipMalloc,
+ *     no hipDeviceSynchronize, no host<->device copy of results => hipGraph-capturable;
+ *   - return value: 0 = ok, >0 = a hipError_t, <0 = SE3TN_E_*; se3tn_last_error() has the text;
+ *   - one context per (process, device); a context is thread-compatible, not thread-safe.
+ */
+#ifndef SE3TRACKNET_H
+#define SE3TRACKNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SE3TN_OK 0
+#define SE3TN_E_ARG (-1)      /* bad argument (NULL, n > max_batch, ...)            */
+#define SE3TN_E_STATE (-2)    /* call order (weights not bound, ...)                */
+#define SE3TN_E_SHAPE (-3)    /* tensor shape does not match Se3TrackNet.state_dict */
+#define SE3TN_E_KEY (-4)      /* unknown / missing state_dict key                   */
+#define SE3TN_E_DEVICE (-5)   /* not a gfx950 device                                */
+
+#define SE3TN_RES 176         /* dataset_info.yml `resolution` (predict.py:130)     */
+
+/* input tensor layouts accepted by se3tn_infer */
+#define SE3TN_NCHW 0 /* float32 [N,4,176,176], channels R,G,B,D: the reference operator
+                        boundary `self.model(dataA, dataB)` predict.py:270-271            */
+#define SE3TN_NHWC 1 /* float32 [N,176,176,4]: what se3tn_preprocess writes               */
+
+typedef struct se3tn_ctx se3tn_ctx;
+
+const char* se3tn_version(void);
+const char* se3tn_last_error(void);
+
+/* ---- life cycle ------------------------------------------------------------------------- */
+/* Replaces `Se3TrackNet(image_size).cuda().eval()` (predict.py:155-158): selects `device`,
+ * checks it is gfx950, allocates the activation workspace for up to `max_batch` pairs. */
+int se3tn_create(int device, int max_batch, se3tn_ctx** out);
+void se3tn_destroy(se3tn_ctx* ctx);
+int se3tn_max_batch(const se3tn_ctx* ctx);
+
+/* ---- weights: `model.load_state_dict(checkpoint['state_dict'])` (predict.py:151-156) ------ */
+/* Hand over one float32 entry of Se3TrackNet.state_dict() (host memory, contiguous, the key and
+ * shape exactly as torch saved them; int64 `num_batches_tracked` entries are not passed). */
+int se3tn_set_tensor(se3tn_ctx* ctx, const char* key, const float* host_data,
+                     const int64_t* shape, int ndim);
+/* After all 106 tensors: fold BatchNorm (eval mode, eps=1e-5, float64 math) into the
+ * convolutions and pack into the device layout (host side).  Fails with SE3TN_E_KEY if a
+ * tensor is missing. */
+int se3tn_pack_weights(se3tn_ctx* ctx);
+size_t se3tn_packed_bytes(const se3tn_ctx* ctx);     /* size of the packed blob          */
+const void* se3tn_packed_host(const se3tn_ctx* ctx); /* host pointer, valid after pack   */
+/* Single-GPU: library-owned device copy of the packed blob. */
+int se3tn_upload_weights(se3tn_ctx* ctx, void* stream);
+/* Multi-GPU: use a caller-owned device blob in packed format (rank 0 packs, RCCL broadcasts
+ * the bytes, every rank binds its copy).  The blob must outlive the context. */
+int se3tn_bind_weights(se3tn_ctx* ctx, const void* device_blob, size_t bytes);
+
+/* ---- per-dataset constants --------------------------------------------------------------- */
+/* mean.npy / std.npy: float64[8] = A(R,G,B,D), B(R,G,B,D) (predict.py:657-658). */
+int se3tn_set_normalization(se3tn_ctx* ctx, const double mean[8], const double std[8]);
+/* trans_normalizer / rot_normalizer of Tracker.__init__ (predict.py:128). */
+int se3tn_set_normalizers(se3tn_ctx* ctx, double trans_normalizer, double rot_normalizer);
+
+/* ---- pre-processing: crop_bbox + OffsetDepth + NormalizeChannels + ToTensor --------------- */
+/* One 176x176 crop (Utils.py:320-359, data_augmentation.py:124-189).  For the rendered image A
+ * pass the 176x176 render itself with window (0,0,176,176). */
+typedef struct se3tn_crop {
+  const uint8_t* rgb;    /* device, [H,W,3] uint8 RGB                                     */
+  const uint16_t* depth; /* device, [H,W] uint16 millimetres                              */
+  int32_t H, W;          /* frame size                                                    */
+  int32_t left, top, right, bottom; /* crop window = min/max of compute_bbox's (v,u) corners;
+                                       may leave the frame (zero padding, Utils.py:330-342) */
+  double z_offset_mm;    /* poseA[2,3]*1000 (data_augmentation.py:137-140; both A and B use
+                            poseA, :130-131); sign handled as the reference does            */
+  int32_t stats;         /* 0: mean[:4]/std[:4] (image A)   1: mean[4:]/std[4:] (image B)  */
+  int32_t _pad;
+} se3tn_crop;
+/* `crops` is a HOST array of n descriptors (copied into kernel arguments, no sync);
+ * out_nhwc: device float32 [n,176,176,4]. */
+int se3tn_preprocess(se3tn_ctx* ctx, const se3tn_crop* crops, int n, float* out_nhwc,
+                     void* stream);
+/* the context's own NHWC input buffers ([max_batch,176,176,4] float32), which = 0 (A) / 1 (B) */
+float* se3tn_input_buffer(se3tn_ctx* ctx, int which);
+
+/* ---- the network + pose update ------------------------------------------------------------ */
+/* Replaces `self.model(dataA,dataB)` (predict.py:270-271 -> se3_tracknet.py:81-112) and, when
+ * poseA/poseB are given, `TrackDataset.processPredict` (datasets.py:159-175) for each pair.
+ *   A, B     device float32, layout per `layout`, n pairs (A or B may be the context's own
+ *            input buffers)
+ *   trans,rot device float32 [n,3] (tanh outputs, as prediction['trans'/'rot']); may be NULL
+ *   poseA    device float64 [n,16] row-major 4x4 object-in-camera (metres); may be NULL
+ *   poseB    device float64 [n,16]: t_B = trans*tn + t_A,  R_B = Rodrigues(rot*rn) . R_A     */
+int se3tn_infer(se3tn_ctx* ctx, const float* A, const float* B, int n, int layout, float* trans,
+                float* rot, const double* poseA, double* poseB, void* stream);
+/* output['feature'] (se3_tracknet.py:96): device float32 [n,256,22,22] NCHW, valid after infer */
+int se3tn_get_feature(se3tn_ctx* ctx, int n, float* feature_nchw, void* stream);
+/* pre-tanh FC outputs of the last se3tn_infer: device float32 [max_batch,6] (trans, rot) */
+const float* se3tn_logits(se3tn_ctx* ctx);
+
+/* ---- host-side pieces of the path (pure CPU, float64, as the reference computes them) ----- */
+/* Utils.py:302-316 compute_bbox with scale (1000,1000,1000): pose row-major 4x4 (metres), K
+ * row-major 3x3, width in mm; out_vu[8] = 4 x (v,u) int32, np.round (half-to-even). */
+int se3tn_compute_bbox(const double pose[16], const double K[9], double object_width_mm,
+                       int32_t out_vu[8]);
+/* datasets.py:159-175 processPredict on the host. */
+int se3tn_pose_update_host(const double poseA[16], const float trans[3], const float rot[3],
+                           double trans_normalizer, double rot_normalizer, double poseB[16]);
+
+/* ---- introspection for tests / profiling --------------------------------------------------- */
+/* Device pointer + geometry of an internal NHWC activation buffer after se3tn_infer.
+ * names: "stem" [n,88,88,128] "pool" "t64" "q64" [n,44,44,128] (channels 0-63 branch A, 64-127
+ * branch B), "ab" "ab_t" [n,22,22,256], "head" "head_t" [n,11,11,1024] (0-511 trans, 512-1023
+ * rot).  dims = {H, W, C}. */
+int se3tn_debug_buffer(se3tn_ctx* ctx, const char* name, const float** ptr, int32_t dims[3]);
+/* stream-ordered device-to-device copy (lets a ctypes host wrap the raw pointers above into its
+ * own tensors without a second HIP binding) */
+int se3tn_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+/* Timing hooks used by bench.py: time of the dominant kernel family (3x3 MFMA convolutions)
+ * inside the LAST se3tn_infer, measured with hipEvents on `stream` when enabled (the events
+ * are recorded around each conv launch; reading them synchronises). */
+int se3tn_profile_enable(se3tn_ctx* ctx, int on);
+int se3tn_profile_read(se3tn_ctx* ctx, float* conv_ms, int* conv_launches, float* total_ms);
+/* Per-launch breakdown of the last se3tn_infer: fills up to `cap` names / milliseconds, returns
+ * the number of launches (>= 0) or an error (< 0 is impossible here: errors are > 0 hipError_t or
+ * SE3TN_E_STATE). */
+int se3tn_profile_launches(se3tn_ctx* ctx, int cap, const char** names, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SE3TRACKNET_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of libse3tracknet.so (C ABI: include/se3tracknet.h).
+
+The HIP library IS the product path: there is no CPU / PyTorch fallback.  If the shared object
+is missing this module raises ImportError telling how to build it; a compute call on a box
+without a gfx950 GPU fails in se3tn_create with SE3TN_E_DEVICE / a hipError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libse3tracknet.so")
+
+NCHW, NHWC = 0, 1
+RES = 176
+
+
+class Se3tnError(RuntimeError):
+    pass
+
+
+class Crop(C.Structure):
+    """se3tn_crop (include/se3tracknet.h)."""
+    _fields_ = [("rgb", C.c_void_p), ("depth", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32),
+                ("left", C.c_int32), ("top", C.c_int32), ("right", C.c_int32), ("bottom", C.c_int32),
+                ("z_offset_mm", C.c_double), ("stats", C.c_int32), ("_pad", C.c_int32)]
+
+
+_SIGS = {
+    "se3tn_version": (C.c_char_p, []),
+    "se3tn_last_error": (C.c_char_p, []),
+    "se3tn_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "se3tn_destroy": (None, [C.c_void_p]),
+    "se3tn_max_batch": (C.c_int, [C.c_void_p]),
+    "se3tn_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "se3tn_pack_weights": (C.c_int, [C.c_void_p]),
+    "se3tn_packed_bytes": (C.c_size_t, [C.c_void_p]),
+    "se3tn_packed_host": (C.c_void_p, [C.c_void_p]),
+    "se3tn_upload_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "se3tn_bind_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "se3tn_set_normalization": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "se3tn_set_normalizers": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "se3tn_preprocess": (C.c_int, [C.c_void_p, C.POINTER(Crop), C.c_int, C.c_void_p, C.c_void_p]),
+    "se3tn_input_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "se3tn_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "se3tn_get_feature": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "se3tn_logits": (C.c_void_p, [C.c_void_p]),
+    "se3tn_compute_bbox": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
+                                     C.POINTER(C.c_int32)]),
+    "se3tn_pose_update_host": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                         C.c_double, C.c_double, C.POINTER(C.c_double)]),
+    "se3tn_debug_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
+    "se3tn_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "se3tn_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "se3tn_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "se3tn_profile_launches": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  torch is imported first so that the process keeps a single
+    HIP runtime: torch's bundled libamdhip64.so.7 has the same SONAME as /opt/rocm's and the
+    dynamic loader reuses the already-loaded one for our NEEDED entry."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            "HIP extension %s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C %s/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % (LIB_PATH, _HERE))
+    import torch  # noqa: F401  (loads the HIP runtime this library must share)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError = header/library drift: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().se3tn_last_error().decode()
+        raise Se3tnError("%s failed (rc=%d): %s" % (what or "se3tn call", rc, msg))

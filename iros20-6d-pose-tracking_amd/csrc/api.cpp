@@ -1,0 +1,389 @@
+// C ABI of the hot path (include/se3tracknet.h).  Host orchestration only: every kernel lives in
+// the .hip files.  One context per (process, device).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "se3tn_internal.h"
+#include "weights.h"
+
+using namespace se3tn;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+static int hipfail(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return (int)e;
+}
+#define HIPCHK(x)                                  \
+  do {                                             \
+    hipError_t _e = (x);                           \
+    if (_e != hipSuccess) return hipfail(_e, #x);  \
+  } while (0)
+
+enum { MAX_LAUNCHES = 24 };
+
+struct se3tn_ctx {
+  int device = -1, max_batch = 0;
+  TensorMap tensors;
+  std::vector<float> packed;
+  float* blob_owned = nullptr;
+  const float* blob = nullptr;
+  BlobLayout L;
+  // activations (NHWC float32)
+  float *inA = nullptr, *inB = nullptr;         // [mb,176,176,4]
+  float* stem = nullptr;                        // [mb,88,88,128]
+  float *pool = nullptr, *t64 = nullptr, *q64 = nullptr;  // [mb,44,44,128]
+  float *ab = nullptr, *ab_t = nullptr;         // [mb,22,22,256]
+  float *head = nullptr, *head_t = nullptr;     // [mb,11,11,1024]
+  float* logits = nullptr;                      // [mb,6]
+  double mean[8], stdv[8];
+  bool have_norm = false;
+  double tn = 0.03, rn = 5.0 * 3.14159265358979323846 / 180.0;
+  // profiling
+  bool prof = false;
+  hipEvent_t ev[MAX_LAUNCHES + 1];
+  bool ev_init = false;
+  int n_launch = 0;
+  const char* names[MAX_LAUNCHES];
+  bool is_conv[MAX_LAUNCHES];
+};
+
+extern "C" {
+
+const char* se3tn_version(void) { return "se3tracknet-gfx950 0.1.0 (blob v2)"; }
+const char* se3tn_last_error(void) { return g_err.c_str(); }
+
+int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
+  if (!out || max_batch < 1) return fail(SE3TN_E_ARG, "se3tn_create: bad argument");
+  se3tn_ctx* c = new se3tn_ctx();
+  c->device = device;
+  c->max_batch = max_batch;
+  c->L = blob_layout();
+  for (int i = 0; i < 8; ++i) { c->mean[i] = 0.0; c->stdv[i] = 1.0; }
+  if (device >= 0) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { delete c; return hipfail(e, "hipGetDeviceProperties"); }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      std::string a = prop.gcnArchName;
+      delete c;
+      return fail(SE3TN_E_DEVICE, "device is " + a + ", this library is built for gfx950 only");
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { delete c; return hipfail(e, "hipSetDevice"); }
+    const size_t mb = (size_t)max_batch;
+    struct { float** p; size_t words; } bufs[] = {
+        {&c->inA, mb * RES * RES * 4},   {&c->inB, mb * RES * RES * 4},
+        {&c->stem, mb * S1 * S1 * 128},  {&c->pool, mb * S2 * S2 * 128},
+        {&c->t64, mb * S2 * S2 * 128},   {&c->q64, mb * S2 * S2 * 128},
+        {&c->ab, mb * S3 * S3 * 256},    {&c->ab_t, mb * S3 * S3 * 256},
+        {&c->head, mb * S4 * S4 * 1024}, {&c->head_t, mb * S4 * S4 * 1024},
+        {&c->logits, mb * 6}};
+    for (auto& b : bufs) {
+      e = hipMalloc((void**)b.p, b.words * sizeof(float));
+      if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(workspace)"); }
+    }
+  }
+  *out = c;
+  return SE3TN_OK;
+}
+
+void se3tn_destroy(se3tn_ctx* c) {
+  if (!c) return;
+  if (c->device >= 0) {
+    float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
+                     c->head_t, c->logits, c->blob_owned};
+    for (float* b : bufs)
+      if (b) (void)hipFree(b);
+    if (c->ev_init)
+      for (auto& e : c->ev) (void)hipEventDestroy(e);
+  }
+  delete c;
+}
+
+int se3tn_max_batch(const se3tn_ctx* c) { return c ? c->max_batch : 0; }
+
+int se3tn_set_tensor(se3tn_ctx* c, const char* key, const float* data, const int64_t* shape, int ndim) {
+  if (!c || !key || !data || !shape || ndim < 1 || ndim > 4) return fail(SE3TN_E_ARG, "se3tn_set_tensor: bad argument");
+  for (const ExpectedTensor& e : expected_tensors()) {
+    if (e.key != key) continue;
+    if ((int)e.shape.size() != ndim) return fail(SE3TN_E_SHAPE, std::string("rank mismatch for ") + key);
+    size_t count = 1;
+    for (int i = 0; i < ndim; ++i) {
+      if (shape[i] != e.shape[i]) return fail(SE3TN_E_SHAPE, std::string("shape mismatch for ") + key);
+      count *= (size_t)shape[i];
+    }
+    StoredTensor& t = c->tensors[key];
+    t.shape.assign(shape, shape + ndim);
+    t.data.assign(data, data + count);
+    return SE3TN_OK;
+  }
+  return fail(SE3TN_E_KEY, std::string("unexpected state_dict key: ") + key);
+}
+
+int se3tn_pack_weights(se3tn_ctx* c) {
+  if (!c) return fail(SE3TN_E_ARG, "null ctx");
+  std::string err = pack_blob(c->tensors, c->packed);
+  if (!err.empty()) return fail(SE3TN_E_KEY, err);
+  c->tensors.clear();
+  return SE3TN_OK;
+}
+
+size_t se3tn_packed_bytes(const se3tn_ctx* c) { return c ? c->L.total * sizeof(float) : 0; }
+const void* se3tn_packed_host(const se3tn_ctx* c) { return (c && !c->packed.empty()) ? c->packed.data() : nullptr; }
+
+int se3tn_upload_weights(se3tn_ctx* c, void* stream) {
+  if (!c || c->device < 0) return fail(SE3TN_E_ARG, "se3tn_upload_weights: no device context");
+  if (c->packed.empty()) return fail(SE3TN_E_STATE, "se3tn_upload_weights: call se3tn_pack_weights first");
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->blob_owned) HIPCHK(hipMalloc((void**)&c->blob_owned, c->L.total * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(c->blob_owned, c->packed.data(), c->L.total * sizeof(float), hipMemcpyHostToDevice,
+                        (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));  // init-time only: the host vector may go away
+  c->blob = c->blob_owned;
+  return SE3TN_OK;
+}
+
+int se3tn_bind_weights(se3tn_ctx* c, const void* device_blob, size_t bytes) {
+  if (!c || c->device < 0 || !device_blob) return fail(SE3TN_E_ARG, "se3tn_bind_weights: bad argument");
+  if (bytes != c->L.total * sizeof(float)) return fail(SE3TN_E_SHAPE, "se3tn_bind_weights: blob size mismatch");
+  uint32_t hdr[4];
+  HIPCHK(hipMemcpy(hdr, device_blob, sizeof(hdr), hipMemcpyDeviceToHost));  // init-time validation
+  if (hdr[0] != BLOB_MAGIC || hdr[1] != BLOB_VERSION || hdr[2] != (uint32_t)c->L.total)
+    return fail(SE3TN_E_SHAPE, "se3tn_bind_weights: bad blob header");
+  c->blob = (const float*)device_blob;
+  return SE3TN_OK;
+}
+
+int se3tn_set_normalization(se3tn_ctx* c, const double mean[8], const double stdv[8]) {
+  if (!c || !mean || !stdv) return fail(SE3TN_E_ARG, "se3tn_set_normalization: bad argument");
+  std::memcpy(c->mean, mean, sizeof(c->mean));
+  std::memcpy(c->stdv, stdv, sizeof(c->stdv));
+  c->have_norm = true;
+  return SE3TN_OK;
+}
+
+int se3tn_set_normalizers(se3tn_ctx* c, double tn, double rn) {
+  if (!c) return fail(SE3TN_E_ARG, "null ctx");
+  c->tn = tn;
+  c->rn = rn;
+  return SE3TN_OK;
+}
+
+float* se3tn_input_buffer(se3tn_ctx* c, int which) { return !c ? nullptr : (which == 0 ? c->inA : c->inB); }
+
+int se3tn_preprocess(se3tn_ctx* c, const se3tn_crop* crops, int n, float* out, void* stream) {
+  if (!c || c->device < 0 || !crops || !out || n < 0) return fail(SE3TN_E_ARG, "se3tn_preprocess: bad argument");
+  if (!c->have_norm) return fail(SE3TN_E_STATE, "se3tn_preprocess: call se3tn_set_normalization first");
+  for (int i = 0; i < n; ++i) {
+    const se3tn_crop& k = crops[i];
+    if (!k.rgb || !k.depth || k.H < 1 || k.W < 1 || k.right <= k.left || k.bottom <= k.top || (k.stats & ~1))
+      return fail(SE3TN_E_ARG, "se3tn_preprocess: bad crop descriptor " + std::to_string(i));
+  }
+  CropArgs a;
+  std::memcpy(a.mean, c->mean, sizeof(a.mean));
+  std::memcpy(a.stdv, c->stdv, sizeof(a.stdv));
+  for (int i0 = 0; i0 < n; i0 += CropArgs::MAX) {
+    a.n = (n - i0 < CropArgs::MAX) ? n - i0 : CropArgs::MAX;
+    std::memcpy(a.c, crops + i0, sizeof(se3tn_crop) * a.n);
+    a.out = out + (size_t)i0 * RES * RES * 4;
+    HIPCHK(launch_preprocess(a, (hipStream_t)stream));
+  }
+  return SE3TN_OK;
+}
+
+static int prof_mark(se3tn_ctx* c, hipStream_t st, const char* name, bool is_conv) {
+  if (!c->prof) return 0;
+  if (c->n_launch >= MAX_LAUNCHES) return 0;
+  c->names[c->n_launch] = name;
+  c->is_conv[c->n_launch] = is_conv;
+  ++c->n_launch;
+  return (int)hipEventRecord(c->ev[c->n_launch], st);
+}
+
+int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout, float* trans, float* rot,
+                const double* poseA, double* poseB, void* stream) {
+  if (!c || c->device < 0 || !A || !B) return fail(SE3TN_E_ARG, "se3tn_infer: bad argument");
+  if (n < 1 || n > c->max_batch) return fail(SE3TN_E_ARG, "se3tn_infer: n outside [1, max_batch]");
+  if (!c->blob) return fail(SE3TN_E_STATE, "se3tn_infer: weights not uploaded/bound");
+  if ((poseA == nullptr) != (poseB == nullptr)) return fail(SE3TN_E_ARG, "se3tn_infer: poseA and poseB go together");
+  if (layout != SE3TN_NCHW && layout != SE3TN_NHWC) return fail(SE3TN_E_ARG, "se3tn_infer: bad layout");
+  hipStream_t st = (hipStream_t)stream;
+  const float* W = c->blob;
+  const BlobLayout& L = c->L;
+  c->n_launch = 0;
+  if (c->prof) HIPCHK(hipEventRecord(c->ev[0], st));
+
+  if (layout == SE3TN_NCHW) {
+    HIPCHK(launch_nchw_to_nhwc4(A, c->inA, n, st));
+    HIPCHK(launch_nchw_to_nhwc4(B, c->inB, n, st));
+    HIPCHK((hipError_t)prof_mark(c, st, "nchw_to_nhwc4 x2", false));
+    A = c->inA;
+    B = c->inB;
+  }
+  HIPCHK(launch_stem(A, B, W + L.stem_w, W + L.stem_b, c->stem, n, st));
+  HIPCHK((hipError_t)prof_mark(c, st, "stem7x7_mfma", false));
+  HIPCHK(launch_maxpool(c->stem, c->pool, n, st));
+  HIPCHK((hipError_t)prof_mark(c, st, "maxpool3x3s2", false));
+
+  auto conv = [&](ConvId id, const float* in, int in_ld, int in_gs, const float* res, int res_ld, int res_gs,
+                  float* out, int out_ld, int out_gs, int hin, int stride, int epi, const char* name) -> int {
+    const Conv3& s = conv_specs()[id];
+    ConvArgs a{};
+    a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id]; a.res = res; a.out = out;
+    a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
+    a.H = hin; a.W = hin; a.Ho = (hin - 1) / stride + 1; a.Wo = a.Ho;
+    a.M = n * a.Ho * a.Wo;
+    a.groups = s.groups;
+    a.in_gs = in_gs; a.res_gs = res_gs; a.out_gs = out_gs; a.bias_gs = s.cout;
+    a.w_gs = (long long)conv3_words(s.cin, s.cout);
+    hipError_t e = launch_conv3x3(a, s.cin, s.cout, stride, epi, st);
+    if (e != hipSuccess) return hipfail(e, name);
+    return prof_mark(c, st, name, true);
+  };
+  int rc;
+  // 64-channel trunk: pool = a0|b0 ; t64 scratch ; q64 = a1|b1 -> a1|b2 (== torch.cat((a,b),1))
+  if ((rc = conv(L64_1, c->pool, 128, 64, nullptr, 0, 0, c->t64, 128, 64, S2, 1, 0, "conv64 A2.conv1|B2.conv1"))) return rc;
+  if ((rc = conv(L64_2, c->t64, 128, 64, c->pool, 128, 64, c->q64, 128, 64, S2, 1, 1, "conv64 A2.conv2|B2.conv2"))) return rc;
+  if ((rc = conv(L64_3, c->q64 + 64, 128, 0, nullptr, 0, 0, c->t64 + 64, 128, 0, S2, 1, 0, "conv64 B3.conv1"))) return rc;
+  if ((rc = conv(L64_4, c->t64 + 64, 128, 0, c->q64 + 64, 128, 0, c->q64 + 64, 128, 0, S2, 1, 1, "conv64 B3.conv2"))) return rc;
+  if ((rc = conv(LAB1, c->q64, 128, 0, nullptr, 0, 0, c->ab, 256, 0, S2, 2, 2, "convAB1 s2"))) return rc;
+  if ((rc = conv(LAB2_1, c->ab, 256, 0, nullptr, 0, 0, c->ab_t, 256, 0, S3, 1, 0, "convAB2.conv1"))) return rc;
+  if ((rc = conv(LAB2_2, c->ab_t, 256, 0, c->ab, 256, 0, c->ab, 256, 0, S3, 1, 1, "convAB2.conv2"))) return rc;
+  if ((rc = conv(LH1, c->ab, 256, 0, nullptr, 0, 0, c->head, 1024, 0, S3, 2, 2, "trans|rot conv1 s2"))) return rc;
+  if ((rc = conv(LH2_1, c->head, 1024, 512, nullptr, 0, 0, c->head_t, 1024, 512, S4, 1, 0, "trans|rot conv2.conv1"))) return rc;
+  if ((rc = conv(LH2_2, c->head_t, 1024, 512, c->head, 1024, 512, c->head, 1024, 512, S4, 1, 1, "trans|rot conv2.conv2"))) return rc;
+
+  HIPCHK(launch_tail(c->head, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st));
+  HIPCHK((hipError_t)prof_mark(c, st, "tail avgpool+fc+tanh+pose", false));
+  return SE3TN_OK;
+}
+
+int se3tn_get_feature(se3tn_ctx* c, int n, float* feature_nchw, void* stream) {
+  if (!c || c->device < 0 || !feature_nchw || n < 1 || n > c->max_batch) return fail(SE3TN_E_ARG, "se3tn_get_feature: bad argument");
+  HIPCHK(launch_nhwc_to_nchw(c->ab, feature_nchw, n, S3 * S3, 256, (hipStream_t)stream));
+  return SE3TN_OK;
+}
+
+const float* se3tn_logits(se3tn_ctx* c) { return c ? c->logits : nullptr; }
+
+int se3tn_debug_buffer(se3tn_ctx* c, const char* name, const float** ptr, int32_t dims[3]) {
+  if (!c || !name || !ptr || !dims) return fail(SE3TN_E_ARG, "se3tn_debug_buffer: bad argument");
+  struct { const char* n; const float* p; int h, w, ch; } t[] = {
+      {"inA", c->inA, RES, RES, 4},      {"inB", c->inB, RES, RES, 4},     {"stem", c->stem, S1, S1, 128},
+      {"pool", c->pool, S2, S2, 128},    {"t64", c->t64, S2, S2, 128},     {"q64", c->q64, S2, S2, 128},
+      {"ab", c->ab, S3, S3, 256},        {"ab_t", c->ab_t, S3, S3, 256},   {"head", c->head, S4, S4, 1024},
+      {"head_t", c->head_t, S4, S4, 1024}};
+  for (auto& e : t)
+    if (std::strcmp(e.n, name) == 0) {
+      *ptr = e.p; dims[0] = e.h; dims[1] = e.w; dims[2] = e.ch;
+      return SE3TN_OK;
+    }
+  return fail(SE3TN_E_KEY, std::string("unknown buffer ") + name);
+}
+
+int se3tn_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+  if (!dst || !src) return fail(SE3TN_E_ARG, "se3tn_memcpy_d2d: null pointer");
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return SE3TN_OK;
+}
+
+int se3tn_profile_enable(se3tn_ctx* c, int on) {
+  if (!c || c->device < 0) return fail(SE3TN_E_ARG, "se3tn_profile_enable: no device context");
+  if (on && !c->ev_init) {
+    for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+    c->ev_init = true;
+  }
+  c->prof = on != 0;
+  c->n_launch = 0;
+  return SE3TN_OK;
+}
+
+int se3tn_profile_read(se3tn_ctx* c, float* conv_ms, int* conv_launches, float* total_ms) {
+  if (!c || !c->prof || c->n_launch == 0) return fail(SE3TN_E_STATE, "se3tn_profile_read: nothing recorded");
+  HIPCHK(hipEventSynchronize(c->ev[c->n_launch]));
+  float conv = 0.f, tot = 0.f;
+  int nconv = 0;
+  for (int i = 0; i < c->n_launch; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+    tot += ms;
+    if (c->is_conv[i]) { conv += ms; ++nconv; }
+  }
+  if (conv_ms) *conv_ms = conv;
+  if (conv_launches) *conv_launches = nconv;
+  if (total_ms) *total_ms = tot;
+  return SE3TN_OK;
+}
+
+int se3tn_profile_launches(se3tn_ctx* c, int cap, const char** names, float* ms) {
+  if (!c || !c->prof || c->n_launch == 0) return fail(SE3TN_E_STATE, "se3tn_profile_launches: nothing recorded");
+  HIPCHK(hipEventSynchronize(c->ev[c->n_launch]));
+  int k = c->n_launch < cap ? c->n_launch : cap;
+  for (int i = 0; i < k; ++i) {
+    if (names) names[i] = c->names[i];
+    if (ms) HIPCHK(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+  }
+  return k;
+}
+
+// ---- host-side float64 pieces -----------------------------------------------------------------
+// np.round: round half to even
+static double round_half_even(double x) { return std::nearbyint(x); }
+
+int se3tn_compute_bbox(const double pose[16], const double K[9], double width, int32_t out_vu[8]) {
+  if (!pose || !K || !out_vu) return fail(SE3TN_E_ARG, "se3tn_compute_bbox: bad argument");
+  // Utils.py:302-316 with scale=(1000,1000,1000)
+  const double x = pose[3] * 1000, y = pose[7] * 1000, z = pose[11] * 1000, off = width / 2;
+  const double px[4] = {x - off, x - off, x + off, x + off};
+  const double py[4] = {y - off, y + off, y - off, y + off};
+  for (int i = 0; i < 4; ++i) {
+    const double u = px[i] * K[0] / z + K[2];
+    const double v = py[i] * K[4] / z + K[5];
+    out_vu[2 * i + 0] = (int32_t)round_half_even(v);
+    out_vu[2 * i + 1] = (int32_t)round_half_even(u);
+  }
+  return SE3TN_OK;
+}
+
+int se3tn_pose_update_host(const double A[16], const float trans[3], const float rot[3], double tn, double rn,
+                           double B[16]) {
+  if (!A || !trans || !rot || !B) return fail(SE3TN_E_ARG, "se3tn_pose_update_host: bad argument");
+  const float tf = (float)tn, rf = (float)rn;
+  const volatile float t0 = trans[0] * tf, t1 = trans[1] * tf, t2 = trans[2] * tf;
+  const volatile float r0 = rot[0] * rf, r1 = rot[1] * rf, r2 = rot[2] * rf;
+  const double rx = r0, ry = r1, rz = r2;
+  double R[9];
+  const double theta = std::sqrt(rx * rx + ry * ry + rz * rz);
+  if (theta < 2.220446049250313e-16) {
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  } else {
+    const double c = std::cos(theta), s = std::sin(theta), c1 = 1.0 - c, it = 1.0 / theta;
+    const double x = rx * it, y = ry * it, z = rz * it;
+    const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+    const double rxm[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    for (int i = 0; i < 9; ++i) R[i] = c * ((i % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[i] + s * rxm[i];
+  }
+  for (int i = 0; i < 9; ++i) R[i] = (double)(float)R[i];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc += R[i * 3 + k] * A[k * 4 + j];
+      B[i * 4 + j] = acc;
+    }
+  B[3] = (double)t0 + A[3];
+  B[7] = (double)t1 + A[7];
+  B[11] = (double)t2 + A[11];
+  B[12] = B[13] = B[14] = 0.0;
+  B[15] = 1.0;
+  return SE3TN_OK;
+}
+
+}  // extern "C"

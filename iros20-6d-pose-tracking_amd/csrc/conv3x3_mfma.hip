@@ -1,0 +1,231 @@
+// 3x3 convolution (pad 1, stride 1|2) + folded-BN bias + {ReLU | residual+ReLU | SELU} as an
+// im2col-free implicit GEMM on the gfx950 exact-f32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces every nn.Conv2d(k=3)+BatchNorm2d(+SELU/ReLU/+identity) of Se3TrackNet
+// (se3_tracknet.py:59-76 via network_modules.py:59-66 ConvBNReLU, :86-120 ResnetBasicBlock).
+//
+// GEMM view: rows = output pixels (n,ho,wo) flattened over the batch, cols = Cout,
+// K = (chunk of 32 input channels) x (tap r,s).  K is walked chunk-major / tap-minor so the 9
+// shifted reads of one 32-channel slab of the input tile happen in 9 consecutive K-steps and are
+// served by L1/L2 (no im2col buffer ever exists).
+//
+// MFMA operand roles are SWAPPED w.r.t. the textbook GEMM: A-operand = weight rows
+// (i = cout), B-operand = pixel rows (j = pixel).  The accumulator then holds, per lane, ONE pixel
+// and 4 runs of 4 consecutive couts  ->  the epilogue is float4 bias / residual / store traffic
+// (16 x dwordx4 per wave instead of 64 x dword).
+//
+// Tile: BM = WM*PT*32 pixels x BN = WN*CT*32 couts per 256-thread workgroup (4 waves, one per SIMD,
+// 2 workgroups per CU).  Per K-step: [BM][32] pixel tile + [BN][32] weight tile staged through
+// registers into double-buffered LDS (rows padded to 36 floats: conflict-free ds_read_b128),
+// one barrier per K-step, next tile's global loads in flight under the current tile's MFMAs.
+#include "se3tn_internal.h"
+
+namespace se3tn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int LDK = 36;  // floats per LDS row: 32 + 4 pad -> row stride 144 B (9 x 16 B, odd)
+
+constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
+constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
+
+__device__ __forceinline__ float selu_f(float v) {
+  return v > 0.f ? SELU_SCALE * v : (SELU_SCALE * SELU_ALPHA) * expm1f(v);
+}
+
+// EPI: 0 = bias+ReLU, 1 = bias+residual+ReLU, 2 = bias+SELU
+template <int EPI>
+__device__ __forceinline__ float4 apply_epilogue(float4 v, const float4 b, const float* res) {
+  v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  if (EPI == 1) {
+    const float4 r = *reinterpret_cast<const float4*>(res);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  if (EPI == 2) {
+    v.x = selu_f(v.x); v.y = selu_f(v.y); v.z = selu_f(v.z); v.w = selu_f(v.w);
+  } else {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  }
+  return v;
+}
+
+template <int CIN, int STRIDE, int WM, int WN, int PT, int CT, int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) {
+  constexpr int BM = WM * PT * 32, BN = WN * CT * 32;
+  constexpr int NCH = CIN / 32, KT = NCH * 9;
+  constexpr int PR = BM / 32, WR = BN / 32;  // rows staged per thread (pixels / weights)
+  constexpr int BUF = (BM + BN) * LDK;       // floats per LDS buffer
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  // workgroup -> (pixel tile, weight panel).  Consecutive workgroup ids land on consecutive XCDs
+  // (id % 8); panels = groups*tiles_n divides 8, so every XCD's L2 only ever sees panels
+  // congruent to its id: a weight panel (<= 2.4 MB) stays resident in that XCD's 4 MB L2.
+  const int panels = a.groups * a.tiles_n;
+  const int p = blockIdx.x % panels, mt = blockIdx.x / panels;
+  const int g = p / a.tiles_n, nt = p % a.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const float* __restrict__ in = a.in + (size_t)g * a.in_gs;
+  const float* __restrict__ wgt = a.w + (size_t)g * a.w_gs;
+
+  // ---- per-thread staging geometry: thread t owns 16-byte column c4 of rows r0 + 32*j ----------
+  const int c4 = tid & 7, r0 = tid >> 3;
+  int rowoff[PR];
+  unsigned rowmask[PR];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int j = 0; j < PR; ++j) {
+    const int m = m0 + r0 + 32 * j;
+    unsigned mask = 0;
+    int off = 0;
+    if (m < a.M) {
+      const int n = m / HoWo, rem = m - n * HoWo;
+      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      const int hi0 = ho * STRIDE - 1, wi0 = wo * STRIDE - 1;
+      off = ((n * a.H + hi0) * a.W + wi0) * a.in_ld + c4 * 4;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          if ((unsigned)(hi0 + r) < (unsigned)a.H && (unsigned)(wi0 + s) < (unsigned)a.W)
+            mask |= 1u << (r * 3 + s);
+    }
+    rowoff[j] = off;
+    rowmask[j] = mask;
+  }
+
+  float4 ra[PR], rb[WR];
+  auto load_tile = [&](int ch, int tap) {
+    const int r = tap / 3, s = tap - r * 3;
+    const int toff = (r * a.W + s) * a.in_ld + ch * 32;
+#pragma unroll
+    for (int j = 0; j < PR; ++j) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((rowmask[j] >> tap) & 1u) v = *reinterpret_cast<const float4*>(in + rowoff[j] + toff);
+      ra[j] = v;
+    }
+    const float* wt = wgt + ((size_t)(ch * 9 + tap) * (a.tiles_n * BN) + n0) * 32 + tid * 4;
+#pragma unroll
+    for (int j = 0; j < WR; ++j) rb[j] = *reinterpret_cast<const float4*>(wt + j * 1024);
+  };
+  auto store_tile = [&](int buf) {
+    float* dst = smem + buf * BUF + r0 * LDK + c4 * 4;
+#pragma unroll
+    for (int j = 0; j < PR; ++j) *reinterpret_cast<float4*>(dst + (32 * j) * LDK) = ra[j];
+#pragma unroll
+    for (int j = 0; j < WR; ++j) *reinterpret_cast<float4*>(dst + (BM + 32 * j) * LDK) = rb[j];
+  };
+
+  f32x16 acc[PT][CT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tile(0, 0);
+  store_tile(0);
+  __syncthreads();
+
+  int ch = 0, tap = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (++tap == 9) { tap = 0; ++ch; }
+    if (kt + 1 < KT) load_tile(ch, tap);
+
+    const float* pP = smem + buf * BUF + (wm * PT * 32 + l31) * LDK + hh * 4;
+    const float* pW = smem + buf * BUF + (BM + wn * CT * 32 + l31) * LDK + hh * 4;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      float pv[PT][4], wv[CT][4];
+#pragma unroll
+      for (int i = 0; i < PT; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(pP + i * 32 * LDK + kg * 8);
+        pv[i][0] = t.x; pv[i][1] = t.y; pv[i][2] = t.z; pv[i][3] = t.w;
+      }
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(pW + j * 32 * LDK + kg * 8);
+        wv[j][0] = t.x; wv[j][1] = t.y; wv[j][2] = t.z; wv[j][3] = t.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+          for (int i = 0; i < PT; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][e], pv[i][e], acc[i][j], 0, 0, 0);
+    }
+
+    if (kt + 1 < KT) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds pixel (l31) x couts {8q + 4hh + 0..3}, q = 0..3, per 32x32 tile ----
+  const float* __restrict__ bias = a.bias + (size_t)g * a.bias_gs;
+  const float* __restrict__ res = (EPI == 1) ? a.res + (size_t)g * a.res_gs : nullptr;
+  float* __restrict__ out = a.out + (size_t)g * a.out_gs;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int m = m0 + (wm * PT + i) * 32 + l31;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = n0 + (wn * CT + j) * 32 + q * 8 + hh * 4;
+        float4 v = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                               acc[i][j][4 * q + 3]);
+        const float4 b = *reinterpret_cast<const float4*>(bias + c);
+        v = apply_epilogue<EPI>(v, b, (EPI == 1) ? res + (size_t)m * a.res_ld + c : nullptr);
+        *reinterpret_cast<float4*>(out + (size_t)m * a.out_ld + c) = v;
+      }
+    }
+  }
+}
+
+template <int CIN, int STRIDE, int WM, int WN, int PT, int CT, int EPI>
+static hipError_t launch_one(ConvArgs a, hipStream_t st) {
+  constexpr int BM = WM * PT * 32, BN = WN * CT * 32;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  auto kern = conv3x3_mfma_kernel<CIN, STRIDE, WM, WN, PT, CT, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles_m = (a.M + BM - 1) / BM;
+  const dim3 grid(tiles_m * a.tiles_n * a.groups);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+// Tile shapes.  Cout=64 layers: 128 pixels x 64 couts (4 waves stacked along pixels);
+// everything else: 128 x 128 (2x2 waves, 2x2 32x32 tiles per wave).
+hipError_t launch_conv3x3(const ConvArgs& a0, int cin, int cout, int stride, int epi, hipStream_t st) {
+  ConvArgs a = a0;
+  if (cin == 64 && cout == 64 && stride == 1) {
+    a.tiles_n = 1;
+    if (epi == 0) return launch_one<64, 1, 4, 1, 1, 2, 0>(a, st);
+    if (epi == 1) return launch_one<64, 1, 4, 1, 1, 2, 1>(a, st);
+  }
+  a.tiles_n = cout / 128;
+  if (cin == 128 && stride == 2 && epi == 2) return launch_one<128, 2, 2, 2, 2, 2, 2>(a, st);
+  if (cin == 256 && stride == 1 && epi == 0) return launch_one<256, 1, 2, 2, 2, 2, 0>(a, st);
+  if (cin == 256 && stride == 1 && epi == 1) return launch_one<256, 1, 2, 2, 2, 2, 1>(a, st);
+  if (cin == 256 && stride == 2 && epi == 2) return launch_one<256, 2, 2, 2, 2, 2, 2>(a, st);
+  if (cin == 512 && stride == 1 && epi == 0) return launch_one<512, 1, 2, 2, 2, 2, 0>(a, st);
+  if (cin == 512 && stride == 1 && epi == 1) return launch_one<512, 1, 2, 2, 2, 2, 1>(a, st);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace se3tn

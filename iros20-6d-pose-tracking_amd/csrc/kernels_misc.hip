@@ -1,0 +1,183 @@
+// Small HBM-bound kernels either side of the convolution stack:
+//   preprocess   crop_bbox + OffsetDepth + NormalizeChannels + ToTensor  (Utils.py:320-359,
+//                data_augmentation.py:124-189)  -> NHWC float4 pixels
+//   nchw_to_nhwc4  adapter for the reference operator boundary (predict.py:267-271)
+//   tail         AdaptiveAvgPool2d(1) + Linear(512,3) + Tanh for both heads
+//                (se3_tracknet.py:72-73,77-78,100-109) + TrackDataset.processPredict
+//                (datasets.py:159-175): t_B = trans*tn + t_A, R_B = Rodrigues(rot*rn) . R_A
+//   nhwc_to_nchw  output['feature'] in the reference's layout
+#include "se3tn_internal.h"
+
+namespace se3tn {
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ in,
+                                                             float* __restrict__ out, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (n, y, x)
+  if (idx >= total) return;
+  constexpr int HW = RES * RES;
+  const int n = idx / HW, p = idx - n * HW;
+  const float* src = in + (size_t)n * 4 * HW + p;
+  float4 v;
+  v.x = src[0]; v.y = src[HW]; v.z = src[2 * HW]; v.w = src[3 * HW];
+  *reinterpret_cast<float4*>(out + (size_t)idx * 4) = v;
+}
+
+hipError_t launch_nchw_to_nhwc4(const float* in, float* out, int n, hipStream_t st) {
+  const int total = n * RES * RES;
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// One thread per output pixel.  Index rule of cv2.resize(INTER_NEAREST) (OpenCV resizeNN):
+//   sx = min(floor(x * (1.0 / ((double)dst / src))), src - 1)      evaluated in float64,
+// the crop canvas is zero outside the frame (Utils.py:327-342).  float64 arithmetic mirrors
+// what NumPy does in the reference: depth offset in f64 then rounded to f32
+// (data_augmentation.py:137-140), (x - mean)/std in f64 then stored as f32 (:160-164, :182-187).
+__global__ __launch_bounds__(256) void preprocess_kernel(const CropArgs a) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= RES * RES) return;
+  const int i = blockIdx.y;
+  const se3tn_crop& c = a.c[i];
+  const int y = p / RES, x = p - y * RES;
+  const int cw = c.right - c.left, chh = c.bottom - c.top;
+  const double ifx = 1.0 / ((double)RES / (double)cw);
+  const double ify = 1.0 / ((double)RES / (double)chh);
+  int sx = (int)floor((double)x * ifx); sx = sx < cw - 1 ? sx : cw - 1;
+  int sy = (int)floor((double)y * ify); sy = sy < chh - 1 ? sy : chh - 1;
+  const int fx = c.left + sx, fy = c.top + sy;
+  float r = 0.f, g = 0.f, b = 0.f, d = 0.f;
+  if ((unsigned)fx < (unsigned)c.W && (unsigned)fy < (unsigned)c.H) {
+    const size_t q = (size_t)fy * c.W + fx;
+    const uint8_t* px = c.rgb + q * 3;
+    r = (float)px[0]; g = (float)px[1]; b = (float)px[2];
+    d = (float)c.depth[q];
+  }
+  const bool invalid = (d <= 100.f) || (d >= 2000.f);
+  const double z = c.z_offset_mm;
+  d = (z < 0.0) ? (float)((double)d + z) : (float)((double)d - z);
+  if (invalid) d = 2000.f;
+  const double* mean = a.mean + 4 * c.stats;
+  const double* sd = a.stdv + 4 * c.stats;
+  float4 o;
+  o.x = (float)(((double)r - mean[0]) / sd[0]);
+  o.y = (float)(((double)g - mean[1]) / sd[1]);
+  o.z = (float)(((double)b - mean[2]) / sd[2]);
+  o.w = (float)(((double)d - mean[3]) / sd[3]);
+  *reinterpret_cast<float4*>(a.out + ((size_t)i * RES * RES + p) * 4) = o;
+}
+
+hipError_t launch_preprocess(const CropArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(preprocess_kernel, dim3((RES * RES + 255) / 256, a.n), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tail: one 256-thread workgroup per pair.  head = [n,11,11,1024] (trans 0-511 | rot 512-1023).
+// Thread t averages channels 4t..4t+3 over the 121 pixels (coalesced 4 KB rows), multiplies by
+// its 3x4 slice of the head's FC matrix; wave-shuffle + LDS reduction over the head's 128 threads.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ head,
+                                                   const float* __restrict__ fc_w,
+                                                   const float* __restrict__ fc_b,
+                                                   float* __restrict__ logits, float* __restrict__ trans,
+                                                   float* __restrict__ rot, const double* __restrict__ poseA,
+                                                   double* __restrict__ poseB, double tn, double rn) {
+  __shared__ float part[4][3];
+  __shared__ float outv[6];
+  const int n = blockIdx.x, t = threadIdx.x;
+  const float* src = head + (size_t)n * (S4 * S4) * 1024 + t * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 11
+  for (int p = 0; p < S4 * S4; ++p) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)p * 1024);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float inv = (float)(S4 * S4);
+  s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv;
+  const int hd = t >> 7;            // 0 trans, 1 rot
+  const int cl = (t & 127) * 4;     // channel within the head
+  float acc[3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    const float4 w = *reinterpret_cast<const float4*>(fc_w + (hd * 3 + o) * 512 + cl);
+    acc[o] = wave_sum(s.x * w.x + s.y * w.y + s.z * w.z + s.w * w.w);
+  }
+  if ((t & 63) == 0) { part[t >> 6][0] = acc[0]; part[t >> 6][1] = acc[1]; part[t >> 6][2] = acc[2]; }
+  __syncthreads();
+  if (t < 6) {
+    const int h = t / 3, o = t - h * 3;
+    const float lg = part[2 * h][o] + part[2 * h + 1][o] + fc_b[h * 4 + o];
+    const float y = tanhf(lg);
+    logits[n * 6 + t] = lg;
+    outv[t] = y;
+    if (h == 0) { if (trans) trans[n * 3 + o] = y; }
+    else        { if (rot) rot[n * 3 + o] = y; }
+  }
+  if (poseA == nullptr) return;
+  __syncthreads();
+  if (t == 0) {
+    const double* A = poseA + (size_t)n * 16;
+    double* B = poseB + (size_t)n * 16;
+    // f32 array * python-float normaliser stays f32 in NumPy (datasets.py:169,172)
+    const float tf = (float)tn, rf = (float)rn;
+    const float tx = outv[0] * tf, ty = outv[1] * tf, tz = outv[2] * tf;
+    const double rx = (double)(outv[3] * rf), ry = (double)(outv[4] * rf), rz = (double)(outv[5] * rf);
+    // cv2.Rodrigues(vec3 float32): double math, result cast back to float32
+    double R[9];
+    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta < 2.220446049250313e-16) {
+      R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    } else {
+      const double c = cos(theta), sn = sin(theta), c1 = 1.0 - c, it = 1.0 / theta;
+      const double x = rx * it, y = ry * it, z = rz * it;
+      R[0] = c + c1 * x * x;      R[1] = c1 * x * y - sn * z;  R[2] = c1 * x * z + sn * y;
+      R[3] = c1 * x * y + sn * z; R[4] = c + c1 * y * y;       R[5] = c1 * y * z - sn * x;
+      R[6] = c1 * x * z - sn * y; R[7] = c1 * y * z + sn * x;  R[8] = c + c1 * z * z;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = (double)(float)R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        B[i * 4 + j] = R[i * 3 + 0] * A[0 * 4 + j] + R[i * 3 + 1] * A[1 * 4 + j] + R[i * 3 + 2] * A[2 * 4 + j];
+    B[3] = (double)tx + A[3];
+    B[7] = (double)ty + A[7];
+    B[11] = (double)tz + A[11];
+    B[12] = 0.0; B[13] = 0.0; B[14] = 0.0; B[15] = 1.0;
+  }
+}
+
+hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
+                       float* trans, float* rot, const double* poseA, double* poseB, double tn,
+                       double rn, int n, hipStream_t st) {
+  hipLaunchKernelGGL(tail_kernel, dim3(n), dim3(256), 0, st, head, fc_w, fc_b, logits, trans, rot,
+                     poseA, poseB, tn, rn);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in,
+                                                            float* __restrict__ out, int hw, int c,
+                                                            int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // output index (n, c, p)
+  if (idx >= total) return;
+  const int p = idx % hw, t = idx / hw;
+  const int ch = t % c, n = t / c;
+  out[idx] = in[((size_t)n * hw + p) * c + ch];
+}
+
+hipError_t launch_nhwc_to_nchw(const float* in, float* out, int n, int hw, int c, hipStream_t st) {
+  const int total = n * hw * c;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, hw, c, total);
+  return hipGetLastError();
+}
+
+}  // namespace se3tn

@@ -1,0 +1,129 @@
+// Internal definitions shared by the host-side weight packer and the gfx950 kernels.
+// Network geometry follows se3_tracknet.py:52-112 of the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/se3tracknet.h"
+
+namespace se3tn {
+
+constexpr int RES = SE3TN_RES;  // 176
+constexpr int S1 = 88;          // after the 7x7 s2 stems
+constexpr int S2 = 44;          // after maxpool 3x3 s2
+constexpr int S3 = 22;          // after convAB1 (s2)
+constexpr int S4 = 11;          // after {trans,rot}_conv1 (s2)
+
+// ---------------------------------------------------------------------------------------------
+// Packed weight blob (float32 words).  One contiguous allocation so that multi-GPU start-up is a
+// single RCCL broadcast.  3x3 convolutions are stored as the MFMA "A" operand panels
+//   [chunk = Cin/32][tap = r*3+s][Cout][32]        (BN folded, see weights.cpp)
+// i.e. for every K-step (chunk,tap) a [Cout][32] row-major tile whose rows are the K-contiguous
+// runs a lane reads with one ds_read_b128.  Stems: [r = 7][Cout = 64][32] with k = s*4+c (s<7).
+// ---------------------------------------------------------------------------------------------
+struct Conv3 {
+  int cin, cout, groups;  // weights of `groups` independent convs stored back to back
+};
+constexpr size_t conv3_words(int cin, int cout) { return (size_t)9 * cin * cout; }
+
+enum ConvId {
+  L64_1 = 0,  // convA2.conv1 | convB2.conv1     (2 groups, 64->64)
+  L64_2,      // convA2.conv2 | convB2.conv2     (2 groups)
+  L64_3,      // convB3.conv1
+  L64_4,      // convB3.conv2
+  LAB1,       // convAB1 128->256 s2
+  LAB2_1,     // convAB2.conv1 256->256
+  LAB2_2,     // convAB2.conv2
+  LH1,        // trans_conv1 | rot_conv1 fused along Cout: 256->1024 s2
+  LH2_1,      // trans_conv2.conv1 | rot_conv2.conv1   (2 groups, 512->512)
+  LH2_2,      // trans_conv2.conv2 | rot_conv2.conv2   (2 groups)
+  NUM_CONV3
+};
+
+struct BlobLayout {
+  // offsets in float32 words
+  size_t stem_w;   // [2 branches][7][64][32]
+  size_t stem_b;   // [2][64]
+  size_t conv_w[NUM_CONV3];
+  size_t conv_b[NUM_CONV3];
+  size_t fc_w;     // [2 heads][3][512]
+  size_t fc_b;     // [2][4] (3 used)
+  size_t total;    // words, incl. the 64-word header
+};
+
+constexpr int HEADER_WORDS = 64;
+constexpr uint32_t BLOB_MAGIC = 0x53453354u;  // 'SE3T'
+constexpr uint32_t BLOB_VERSION = 2;
+
+inline const Conv3* conv_specs() {
+  static const Conv3 s[NUM_CONV3] = {
+      {64, 64, 2},   {64, 64, 2},   {64, 64, 1},   {64, 64, 1},  {128, 256, 1},
+      {256, 256, 1}, {256, 256, 1}, {256, 1024, 1}, {512, 512, 2}, {512, 512, 2}};
+  return s;
+}
+
+inline BlobLayout blob_layout() {
+  BlobLayout L{};
+  size_t o = HEADER_WORDS;
+  L.stem_w = o; o += (size_t)2 * 7 * 64 * 32;
+  L.stem_b = o; o += 2 * 64;
+  const Conv3* s = conv_specs();
+  for (int i = 0; i < NUM_CONV3; ++i) {
+    L.conv_w[i] = o; o += conv3_words(s[i].cin, s[i].cout) * s[i].groups;
+    L.conv_b[i] = o; o += (size_t)s[i].cout * s[i].groups;
+  }
+  L.fc_w = o; o += 2 * 3 * 512;
+  L.fc_b = o; o += 2 * 4;
+  o = (o + 63) & ~(size_t)63;
+  L.total = o;
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel argument blocks
+// ---------------------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* in;    // NHWC, `in_ld` floats per pixel; channel offset already applied
+  const float* w;     // packed panels of group 0
+  const float* bias;  // folded bias of group 0
+  const float* res;   // residual (geometry of out) or nullptr
+  float* out;
+  int in_ld, res_ld, out_ld;
+  int H, W, Ho, Wo;   // input / output spatial size
+  int M;              // n * Ho * Wo  (GEMM rows = output pixels)
+  int tiles_n;        // Cout / BN
+  int groups;         // independent convolutions in this launch
+  int in_gs, res_gs, out_gs, bias_gs;  // per-group strides (floats)
+  long long w_gs;
+};
+
+struct CropArgs {  // one launch handles up to CROPS_PER_LAUNCH crops
+  static constexpr int MAX = 24;
+  se3tn_crop c[MAX];
+  double mean[8], stdv[8];
+  float* out;  // [n,176,176,4]
+  int n;
+};
+
+// launchers (defined in the .hip files)
+hipError_t launch_nchw_to_nhwc4(const float* in, float* out, int n, hipStream_t st);
+hipError_t launch_preprocess(const CropArgs& a, hipStream_t st);
+hipError_t launch_stem(const float* inA, const float* inB, const float* w, const float* bias,
+                       float* out, int n, hipStream_t st);
+hipError_t launch_maxpool(const float* in, float* out, int n, hipStream_t st);
+// conv3x3: cin/cout/stride select the instantiation; epi: 0 bias+relu, 1 bias+res+relu, 2 bias+selu
+hipError_t launch_conv3x3(const ConvArgs& a, int cin, int cout, int stride, int epi, hipStream_t st);
+hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
+                       float* trans, float* rot, const double* poseA, double* poseB, double tn,
+                       double rn, int n, hipStream_t st);
+hipError_t launch_nhwc_to_nchw(const float* in, float* out, int n, int hw, int c, hipStream_t st);
+
+// host-side packer (weights.cpp)
+struct HostTensor {
+  const float* data;
+  int64_t shape[4];
+  int ndim;
+};
+
+}  // namespace se3tn

@@ -1,0 +1,178 @@
+"""Thin Python owner of one se3tn context (one per process / GPU).  PyTorch is used only for
+device memory, streams and (in dist.py) torch.distributed -- all arithmetic is in the HIP library."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NCHW, NHWC, RES, Crop, Se3tnError, check
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    def __init__(self, device=0, max_batch=64):
+        self.lib = _lib.load()
+        self.device = int(device)
+        self.max_batch = int(max_batch)
+        h = C.c_void_p()
+        check(self.lib.se3tn_create(self.device, self.max_batch, C.byref(h)), "se3tn_create")
+        self._h = h
+        self._blob = None  # keeps a bound (caller-owned) weight blob alive
+        self.has_weights = False
+        if self.device >= 0:
+            torch.cuda.set_device(self.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.se3tn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ---------------------------------------------------------------------------
+    def pack_state_dict(self, state_dict):
+        """Hand the reference checkpoint's state_dict (predict.py:151-156) to the library:
+        BN folding + packing happen in C++.  Returns the packed blob as a CPU uint8 tensor."""
+        n = 0
+        for key, t in state_dict.items():
+            if t.dtype != torch.float32:
+                if key.endswith("num_batches_tracked"):
+                    continue
+                raise Se3tnError("state_dict[%s]: expected float32, got %s" % (key, t.dtype))
+            t = t.detach().cpu().contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            check(self.lib.se3tn_set_tensor(self._h, key.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()),
+                  "se3tn_set_tensor(%s)" % key)
+            n += 1
+        check(self.lib.se3tn_pack_weights(self._h), "se3tn_pack_weights")
+        nbytes = self.lib.se3tn_packed_bytes(self._h)
+        host = self.lib.se3tn_packed_host(self._h)
+        buf = (C.c_uint8 * nbytes).from_address(host)
+        return torch.frombuffer(buf, dtype=torch.uint8).clone()
+
+    def load_state_dict(self, state_dict):
+        self.pack_state_dict(state_dict)
+        check(self.lib.se3tn_upload_weights(self._h, _stream_ptr()), "se3tn_upload_weights")
+        self.has_weights = True
+
+    def packed_bytes(self):
+        return int(self.lib.se3tn_packed_bytes(self._h))
+
+    def bind_blob(self, blob_cuda):
+        """Use a caller-owned CUDA uint8 tensor holding the packed blob (e.g. received through
+        an RCCL broadcast)."""
+        assert blob_cuda.is_cuda and blob_cuda.dtype == torch.uint8 and blob_cuda.is_contiguous()
+        torch.cuda.current_stream().synchronize()
+        check(self.lib.se3tn_bind_weights(self._h, C.c_void_p(blob_cuda.data_ptr()), blob_cuda.numel()),
+              "se3tn_bind_weights")
+        self._blob = blob_cuda
+        self.has_weights = True
+
+    # ---- constants -------------------------------------------------------------------------
+    def set_normalization(self, mean, std):
+        m = (C.c_double * 8)(*[float(x) for x in np.asarray(mean).reshape(8)])
+        s = (C.c_double * 8)(*[float(x) for x in np.asarray(std).reshape(8)])
+        check(self.lib.se3tn_set_normalization(self._h, m, s), "se3tn_set_normalization")
+
+    def set_normalizers(self, trans_normalizer, rot_normalizer):
+        check(self.lib.se3tn_set_normalizers(self._h, float(trans_normalizer), float(rot_normalizer)),
+              "se3tn_set_normalizers")
+
+    # ---- compute ---------------------------------------------------------------------------
+    def input_buffer_ptr(self, which):
+        return self.lib.se3tn_input_buffer(self._h, which)
+
+    def preprocess(self, crops, out):
+        """crops: list of dict(rgb=cuda u8 [H,W,3], depth=cuda u16-as-int16/uint16 [H,W],
+        window=(left,top,right,bottom), z_offset_mm=float, stats=0|1).
+        out: cuda float32 tensor [n,176,176,4] or a raw device pointer (int)."""
+        n = len(crops)
+        arr = (Crop * n)()
+        for i, c in enumerate(crops):
+            rgb, depth = c["rgb"], c["depth"]
+            assert rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.is_contiguous() and rgb.shape[2] == 3
+            assert depth.is_cuda and depth.element_size() == 2 and depth.is_contiguous()
+            arr[i].rgb = rgb.data_ptr(); arr[i].depth = depth.data_ptr()
+            arr[i].H, arr[i].W = int(rgb.shape[0]), int(rgb.shape[1])
+            arr[i].left, arr[i].top, arr[i].right, arr[i].bottom = [int(v) for v in c["window"]]
+            arr[i].z_offset_mm = float(c["z_offset_mm"])
+            arr[i].stats = int(c["stats"])
+        ptr = out.data_ptr() if torch.is_tensor(out) else int(out)
+        check(self.lib.se3tn_preprocess(self._h, arr, n, C.c_void_p(ptr), _stream_ptr()), "se3tn_preprocess")
+
+    def infer(self, A, B, n, layout=NCHW, trans=None, rot=None, poseA=None, poseB=None):
+        def p(x):
+            if x is None:
+                return None
+            return C.c_void_p(x.data_ptr() if torch.is_tensor(x) else int(x))
+        check(self.lib.se3tn_infer(self._h, p(A), p(B), int(n), int(layout), p(trans), p(rot), p(poseA), p(poseB),
+                                   _stream_ptr()), "se3tn_infer")
+
+    def feature(self, n):
+        out = torch.empty((n, 256, 22, 22), dtype=torch.float32, device="cuda:%d" % self.device)
+        check(self.lib.se3tn_get_feature(self._h, n, C.c_void_p(out.data_ptr()), _stream_ptr()), "se3tn_get_feature")
+        return out
+
+    def logits(self, n):
+        out = torch.empty((n, 6), dtype=torch.float32, device="cuda:%d" % self.device)
+        check(self.lib.se3tn_memcpy_d2d(C.c_void_p(out.data_ptr()), C.c_void_p(self.lib.se3tn_logits(self._h)),
+                                        n * 6 * 4, _stream_ptr()), "se3tn_memcpy_d2d")
+        return out
+
+    def debug_buffer(self, name, n):
+        """Copy of an internal NHWC activation buffer: float32 cuda tensor [n,H,W,C]."""
+        ptr = C.c_void_p()
+        dims = (C.c_int32 * 3)()
+        check(self.lib.se3tn_debug_buffer(self._h, name.encode(), C.byref(ptr), dims), "se3tn_debug_buffer")
+        out = torch.empty((n, dims[0], dims[1], dims[2]), dtype=torch.float32, device="cuda:%d" % self.device)
+        check(self.lib.se3tn_memcpy_d2d(C.c_void_p(out.data_ptr()), ptr, out.numel() * 4, _stream_ptr()),
+              "se3tn_memcpy_d2d")
+        return out
+
+    # ---- profiling -------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        check(self.lib.se3tn_profile_enable(self._h, 1 if on else 0), "se3tn_profile_enable")
+
+    def profile_read(self):
+        conv = C.c_float(); nl = C.c_int(); tot = C.c_float()
+        check(self.lib.se3tn_profile_read(self._h, C.byref(conv), C.byref(nl), C.byref(tot)), "se3tn_profile_read")
+        return conv.value, nl.value, tot.value
+
+    def profile_launches(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        k = self.lib.se3tn_profile_launches(self._h, 32, names, ms)
+        if k < 0:
+            check(k, "se3tn_profile_launches")
+        return [(names[i].decode(), ms[i]) for i in range(k)]
+
+
+# ---- host-side float64 helpers (pure CPU entry points of the C ABI) ---------------------------
+def compute_bbox(pose, K, object_width_mm):
+    """Utils.py:302-316 with scale=(1000,1000,1000): int32 [4,2] (v,u)."""
+    lib = _lib.load()
+    p = (C.c_double * 16)(*np.asarray(pose, np.float64).reshape(16))
+    k = (C.c_double * 9)(*np.asarray(K, np.float64).reshape(9))
+    out = (C.c_int32 * 8)()
+    check(lib.se3tn_compute_bbox(p, k, float(object_width_mm), out), "se3tn_compute_bbox")
+    return np.array(out[:], dtype=np.int32).reshape(4, 2)
+
+
+def pose_update_host(A_in_cam, trans, rot, trans_normalizer, rot_normalizer):
+    """datasets.py:159-175 processPredict (host float64)."""
+    lib = _lib.load()
+    a = (C.c_double * 16)(*np.asarray(A_in_cam, np.float64).reshape(16))
+    t = (C.c_float * 3)(*np.asarray(trans, np.float32).reshape(3))
+    r = (C.c_float * 3)(*np.asarray(rot, np.float32).reshape(3))
+    out = (C.c_double * 16)()
+    check(lib.se3tn_pose_update_host(a, t, r, float(trans_normalizer), float(rot_normalizer), out),
+          "se3tn_pose_update_host")
+    return np.array(out[:], dtype=np.float64).reshape(4, 4)

@@ -1,0 +1,95 @@
+"""Drop-in for the reference's ``predict.Tracker`` (predict.py:127-296): same constructor
+arguments, ``on_track`` signature / return value and the attributes callers read (``K``,
+``object_cloud``, ``object_width``, ``dataset``-less).  The arithmetic of on_track runs on the GPU
+through the C ABI: se3tn_preprocess -> se3tn_infer (network + pose update); only compute_bbox is
+host float64 exactly as the reference.  Rendering (predict.py:193-215) is out of the kernel scope:
+a renderer object is injected (``renderer.render(ob_in_cam, K, window) -> rgb u8, depth u16``)."""
+import numpy as np
+import torch
+
+from . import utils as U
+from .engine import Engine, NHWC
+
+
+class Tracker:
+    def __init__(self, dataset_info, images_mean, images_std, ckpt_dir, model_path=None,
+                 trans_normalizer=0.03, rot_normalizer=5 * np.pi / 180, renderer=None, device=0,
+                 max_samples=8):
+        self.dataset_info = dataset_info
+        self.image_size = (dataset_info['resolution'], dataset_info['resolution'])
+        self.object_cloud = None
+        if model_path is not None:
+            pts = U.load_model_points(model_path)
+            self.object_cloud = U.PointCloud(U.voxel_down_sample(pts, 0.005))
+        if 'object_width' not in dataset_info:
+            if self.object_cloud is None:
+                raise ValueError("dataset_info has no 'object_width' and no model_path was given")
+            object_max_width = U.compute_obj_max_width(self.object_cloud.points)
+            self.object_width = object_max_width + dataset_info['boundingbox'] / 100 * object_max_width
+        else:
+            self.object_width = dataset_info['object_width']
+        self.mean = np.asarray(images_mean, np.float64)
+        self.std = np.asarray(images_std, np.float64)
+        cam = dataset_info['camera']
+        self.K = np.array([cam['focalX'], 0, cam['centerX'], 0, cam['focalY'], cam['centerY'], 0, 0, 1]).reshape(3, 3)
+
+        # checkpoint surface: torch.load(path)['state_dict'] (predict.py:151-156) or a dict
+        checkpoint = torch.load(ckpt_dir, map_location="cpu") if isinstance(ckpt_dir, str) else ckpt_dir
+        sd = checkpoint['state_dict'] if 'state_dict' in checkpoint else checkpoint
+        self.engine = Engine(device, max_samples)
+        self.engine.load_state_dict(sd)
+        self.engine.set_normalization(self.mean, self.std)
+        self.trans_normalizer = float(trans_normalizer)
+        self.rot_normalizer = float(rot_normalizer)
+        self.engine.set_normalizers(self.trans_normalizer, self.rot_normalizer)
+        self.model = self.engine  # attribute name kept for callers that only check it exists
+        self.renderer = renderer
+        self.prev_rgb = None
+        self.prev_depth = None
+        self.frame_cnt = 0
+        self.errs = []
+        dev = "cuda:%d" % device
+        self._dev = dev
+        self._poseA = torch.empty((max_samples, 16), dtype=torch.float64, device=dev)
+        self._poseB = torch.empty((max_samples, 16), dtype=torch.float64, device=dev)
+        self._trans = torch.empty((max_samples, 3), dtype=torch.float32, device=dev)
+        self._rot = torch.empty((max_samples, 3), dtype=torch.float32, device=dev)
+        self.last_prediction = None
+
+    def render_window(self, ob2cam):
+        """predict.py:193-215.  Delegates to the injected renderer with the crop window."""
+        if self.renderer is None:
+            raise RuntimeError("Tracker.render_window: no renderer injected (rendering is outside the HIP hot path)")
+        bbox = U.compute_bbox(ob2cam, self.K, self.object_width, scale=(1000, 1000, 1000))
+        return self.renderer.render(ob2cam, self.K, U.crop_window(bbox))
+
+    def on_track(self, prev_pose, current_rgb, current_depth, gt_A_in_cam=None, gt_B_in_cam=None,
+                 debug=False, samples=1):
+        """predict.py:217-296.  current_rgb HxWx3 uint8 RGB, current_depth HxW uint16 mm,
+        prev_pose 4x4 object-in-camera (metres).  Returns the 4x4 float64 pose estimate."""
+        prev_pose = np.asarray(prev_pose, np.float64)
+        bb = U.compute_bbox(prev_pose, self.K, self.object_width, scale=(1000, 1000, 1000))
+        rgbA, depthA = self.render_window(prev_pose)
+        dev = self._dev
+        rgb_d = torch.from_numpy(np.ascontiguousarray(current_rgb)).to(dev, non_blocking=True)
+        dep_d = torch.from_numpy(np.ascontiguousarray(current_depth).view(np.int16)).to(dev, non_blocking=True)
+        rgbA_d = torch.from_numpy(np.ascontiguousarray(rgbA)).to(dev, non_blocking=True)
+        depA_d = torch.from_numpy(np.ascontiguousarray(depthA).astype(np.uint16).view(np.int16)).to(dev, non_blocking=True)
+        z_mm = float(prev_pose[2, 3]) * 1000
+        res = self.image_size[0]
+        n = int(samples)
+        cropA = dict(rgb=rgbA_d, depth=depA_d, window=(0, 0, res, res), z_offset_mm=z_mm, stats=0)
+        cropB = dict(rgb=rgb_d, depth=dep_d, window=U.crop_window(bb), z_offset_mm=z_mm, stats=1)
+        # the reference evaluates `samples` identical hypotheses (only i==0 sets sample_pose,
+        # predict.py:229-231) and returns the first
+        self.engine.preprocess([cropA] * n, self.engine.input_buffer_ptr(0))
+        self.engine.preprocess([cropB] * n, self.engine.input_buffer_ptr(1))
+        self._poseA[:n].copy_(torch.from_numpy(np.tile(prev_pose.reshape(1, 16), (n, 1))), non_blocking=True)
+        self.engine.infer(self.engine.input_buffer_ptr(0), self.engine.input_buffer_ptr(1), n, NHWC,
+                          self._trans, self._rot, self._poseA, self._poseB)
+        poseB = self._poseB[:n].cpu().numpy().reshape(n, 4, 4)  # D2H + sync, as predict.py:275-276
+        self.last_prediction = dict(trans=self._trans[:n].cpu().numpy(), rot=self._rot[:n].cpu().numpy(), bbox=bb)
+        self.prev_rgb = current_rgb
+        self.prev_depth = current_depth
+        self.frame_cnt += 1
+        return poseB[0]

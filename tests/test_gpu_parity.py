@@ -1,0 +1,213 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes), against the CPU
+oracle and the committed goldens, on the same seeded inputs.
+
+Tolerances (north star): |d(trans, rot)| <= 1e-4 on the network regression, <= 1e-5 on the composed
+4x4 pose.  Pre-tanh logits and every intermediate feature map are compared too (tanh saturation
+and the input-independent part of the logits would otherwise hide errors)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fixtures as Fx
+from oracle import se3_oracle as O
+from oracle.make_golden import ON_TRACK_HEAD_GAIN, PRE_CASES, SUB
+
+NET_TOL = 1e-4     # north-star tolerance on (trans, rot)
+ACT_RTOL = 2e-5    # feature maps: f32 accumulation-order noise (oracle self-noise is ~2e-6)
+POSE_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def se3():
+    import se3tracknet_amd
+    return se3tracknet_amd
+
+
+@pytest.fixture(scope="module")
+def model0(se3):
+    sd = O.make_state_dict(0)
+    m = se3.Se3TrackNet(176, max_batch=64)
+    m.load_state_dict(sd)
+    m.cuda(0).eval()
+    return m, sd
+
+
+def _nchw(t):  # NHWC cuda -> NCHW cpu
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def _close(name, got, want, rtol, atol):
+    got = got.double(); want = want.double()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    worst = float((err - tol).max())
+    assert worst <= 0, "%s: max abs err %.3e (max |ref| %.3e), exceeds tol by %.3e" % (
+        name, float(err.max()), float(want.abs().max()), worst)
+    return float(err.max())
+
+
+def test_single_hip_runtime(se3):
+    torch.zeros(1, device="cuda")
+    libs = {l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}
+    assert len(libs) == 1, libs
+
+
+def test_forward_every_stage_vs_oracle_and_golden(se3, model0, golden_dir):
+    model, sd = model0
+    g = np.load(os.path.join(golden_dir, "network_n3.npz"))
+    A, B = Fx.net_inputs(1, 3)
+    out = model(A.cuda(), B.cuda())
+    torch.cuda.synchronize()
+    ref = O.forward(sd, A, B, intermediates=True)
+    eng = model.engine
+    n = 3
+    stem = _nchw(eng.debug_buffer("stem", n))
+    _close("stemA", stem[:, :64], ref["stemA"], ACT_RTOL, 1e-5)
+    _close("stemB", stem[:, 64:], ref["stemB"], ACT_RTOL, 1e-5)
+    pool = _nchw(eng.debug_buffer("pool", n))
+    _close("poolA", pool[:, :64], ref["poolA"], ACT_RTOL, 1e-5)
+    cat = _nchw(eng.debug_buffer("q64", n))
+    _close("cat(a,b)", cat, ref["cat"], ACT_RTOL, 2e-5)
+    feat = out["feature"].cpu()
+    _close("feature", feat, ref["feature"], ACT_RTOL, 5e-5)
+    head = _nchw(eng.debug_buffer("head", n))
+    _close("trans_conv2", head[:, :512], ref["trans_c2"], ACT_RTOL, 1e-4)
+    _close("rot_conv2", head[:, 512:], ref["rot_c2"], ACT_RTOL, 1e-4)
+    lg = eng.logits(n).cpu()
+    _close("trans_logit", lg[:, :3], ref["trans_logit"], 0, NET_TOL)
+    _close("rot_logit", lg[:, 3:], ref["rot_logit"], 0, NET_TOL)
+    e1 = _close("trans", out["trans"].cpu(), ref["trans"], 0, NET_TOL)
+    e2 = _close("rot", out["rot"].cpu(), ref["rot"], 0, NET_TOL)
+    # and against what the reference's own code produced
+    _close("trans vs golden", out["trans"].cpu(), torch.from_numpy(g["trans"]), 0, NET_TOL)
+    _close("rot vs golden", out["rot"].cpu(), torch.from_numpy(g["rot"]), 0, NET_TOL)
+    _close("feature vs golden", feat[:, ::SUB, ::SUB, ::SUB], torch.from_numpy(g["feature"]), ACT_RTOL, 5e-5)
+    _close("trans_conv2 vs golden", head[:, :512][:, ::SUB, ::SUB, ::SUB], torch.from_numpy(g["act_trans_conv2"]), ACT_RTOL, 1e-4)
+    print("max |d(trans,rot)| = %.2e" % max(e1, e2))
+
+
+def test_forward_big_inputs_second_seed(se3, golden_dir):
+    g = np.load(os.path.join(golden_dir, "network_big_n2.npz"))
+    sd = O.make_state_dict(7, head_gain=0.002)
+    m = se3.Se3TrackNet(176, max_batch=2)
+    m.load_state_dict(sd)
+    m.cuda(0)
+    A, B = Fx.net_inputs(11, 2, scale=40.0)
+    out = m(A.cuda(), B.cuda(), return_feature=False)
+    lg = m.engine.logits(2).cpu()
+    _close("logits", lg, torch.from_numpy(np.concatenate([g["trans_logit"], g["rot_logit"]], 1)), 0, NET_TOL)
+    _close("trans", out["trans"].cpu(), torch.from_numpy(g["trans"]), 0, NET_TOL)
+    _close("rot", out["rot"].cpu(), torch.from_numpy(g["rot"]), 0, NET_TOL)
+
+
+def test_batch64_rows_equal_batch1_and_ragged_tail(se3, model0):
+    """Size-independent property at BASELINE's batch: every pair of a batch-64 call gives the
+    same answer as that pair alone (tiles straddle pair boundaries; 64*1936 etc. are not tile
+    multiples), and n=5 (ragged last tile everywhere) agrees as well."""
+    model, sd = model0
+    A, B = Fx.net_inputs(5, 64)
+    Ac, Bc = A.cuda(), B.cuda()
+    o64 = model(Ac, Bc, return_feature=False)
+    t64, r64 = o64["trans"].clone(), o64["rot"].clone()
+    l64 = model.engine.logits(64).clone()
+    for i in (0, 17, 63):
+        o1 = model(Ac[i:i + 1], Bc[i:i + 1], return_feature=False)
+        l1 = model.engine.logits(1)
+        assert float((l1[0] - l64[i]).abs().max()) < 2e-6
+        assert float((o1["trans"][0] - t64[i]).abs().max()) < 2e-6
+    o5 = model(Ac[10:15], Bc[10:15], return_feature=False)
+    assert float((o5["rot"] - r64[10:15]).abs().max()) < 2e-6
+    # spot-check 2 of the 64 against the CPU oracle
+    ref = O.forward(sd, A[[3, 40]], B[[3, 40]])
+    _close("b64 trans", t64[[3, 40]].cpu(), ref["trans"], 0, NET_TOL)
+    _close("b64 rot", r64[[3, 40]].cpu(), ref["rot"], 0, NET_TOL)
+
+
+def _frame_to_cuda(rgb, depth):
+    return torch.from_numpy(rgb).cuda(), torch.from_numpy(depth.view(np.int16)).cuda()
+
+
+@pytest.mark.parametrize("case", PRE_CASES, ids=[c[0] for c in PRE_CASES])
+def test_preprocess_vs_oracle_and_golden(se3, case, golden_dir):
+    name, fseed, t, width = case
+    g = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    eng = se3.Engine(0, 2)
+    mean, std = Fx.mean_std(0)
+    eng.set_normalization(mean, std)
+    rgb, depth = Fx.synthetic_frame(fseed)
+    P = Fx.pose(fseed, t)
+    rgbA, depthA = Fx.synthetic_render(fseed + 100, t[2])
+    bb = se3.compute_bbox(P, Fx.K_YCB, width)
+    assert (bb == g[name + "_bbox"]).all()
+    r_d, d_d = _frame_to_cuda(rgb, depth)
+    ra_d, da_d = _frame_to_cuda(rgbA, depthA)
+    out = torch.empty((2, 176, 176, 4), dtype=torch.float32, device="cuda")
+    z = float(P[2, 3]) * 1000
+    eng.preprocess([dict(rgb=ra_d, depth=da_d, window=(0, 0, 176, 176), z_offset_mm=z, stats=0),
+                    dict(rgb=r_d, depth=d_d, window=se3.crop_window(bb), z_offset_mm=z, stats=1)], out)
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).contiguous().cpu().numpy()
+    rgbB, depthB = O.crop_bbox(rgb, depth, bb, (176, 176))
+    a, b = O.process_data(rgbA, depthA, P, rgbB, depthB, mean, std)
+    # byte/index work + IEEE float64 arithmetic: bit-exact
+    assert (got[0] == a).all(), float(np.abs(got[0] - a).max())
+    assert (got[1] == b).all(), float(np.abs(got[1] - b).max())
+    assert Fx.sha(got[0]) == str(g[name + "_dataA_sha"])
+    assert Fx.sha(got[1]) == str(g[name + "_dataB_sha"])
+
+
+def test_pose_update_device_vs_golden(se3, model0, golden_dir):
+    """se3tn_infer with poses: compare the device pose composition against processPredict
+    applied (oracle) to the device's own (trans, rot)."""
+    model, sd = model0
+    eng = model.engine
+    A, B = Fx.net_inputs(9, 4)
+    n = 4
+    trans = torch.empty((n, 3), device="cuda"); rot = torch.empty((n, 3), device="cuda")
+    poses = np.stack([Fx.pose(70 + i, (0.01 * i, -0.02, 0.6 + 0.1 * i)) for i in range(n)])
+    pA = torch.from_numpy(poses.reshape(n, 16)).cuda()
+    pB = torch.empty_like(pA)
+    for tn, rn in ((0.03, 5 * np.pi / 180), (0.03, 30 * np.pi / 180)):
+        eng.set_normalizers(tn, rn)
+        eng.infer(A.cuda(), B.cuda(), n, se3.NCHW, trans, rot, pA, pB)
+        torch.cuda.synchronize()
+        for i in range(n):
+            want = O.process_predict(poses[i], trans[i].cpu().numpy(), rot[i].cpu().numpy(), tn, rn)
+            got = pB[i].cpu().numpy().reshape(4, 4)
+            assert np.abs(got - want).max() < 1e-12, np.abs(got - want).max()
+            assert (got[3] == np.array([0, 0, 0, 1.0])).all()
+    eng.set_normalizers(0.03, 5 * np.pi / 180)
+
+
+class _Render:
+    """synthetic stand-in for the renderer (same generator as the golden)."""
+    def __init__(self):
+        self.f = 0
+
+    def render(self, ob2cam, K, window):
+        rgbA, depthA = Fx.synthetic_render(130 + self.f, ob2cam[2, 3])
+        self.f += 1
+        return rgbA, depthA
+
+
+def test_tracker_on_track_vs_reference_golden(se3, golden_dir):
+    """Tracker drop-in: 3 frames with pose feedback, against the goldens produced by the
+    composition of the reference's inner functions (predict.py:217-296)."""
+    g = np.load(os.path.join(golden_dir, "on_track.npz"))
+    sd = O.make_state_dict(0, head_gain=ON_TRACK_HEAD_GAIN)
+    mean, std = Fx.mean_std(0)
+    trk = se3.Tracker(Fx.DATASET_INFO, mean, std, {"state_dict": sd}, model_path=None, renderer=_Render())
+    P = Fx.pose(3)
+    for f in range(3):
+        rgb, depth = Fx.synthetic_frame(30 + f)
+        P = trk.on_track(P, rgb, depth, samples=1)
+        assert P.dtype == np.float64 and P.shape == (4, 4)
+        assert (trk.last_prediction["bbox"] == g["bbox"][f]).all()          # identical integer bbox track
+        assert np.abs(trk.last_prediction["trans"][0] - g["trans"][f]).max() < NET_TOL
+        assert np.abs(trk.last_prediction["rot"][0] - g["rot"][f]).max() < NET_TOL
+        assert np.abs(P - g["poses"][f + 1]).max() < POSE_TOL, np.abs(P - g["poses"][f + 1]).max()
+    assert trk.frame_cnt == 3
