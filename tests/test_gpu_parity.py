@@ -40,10 +40,12 @@ def _nchw(t):  # NHWC cuda -> NCHW cpu
     return t.permute(0, 3, 1, 2).contiguous().cpu()
 
 
-def _close(name, got, want, rtol, atol):
+def _close(name, got, want, rtol, atol, scale_atol=0.0):
+    """|got-want| <= atol + scale_atol*max|want| + rtol*|want| elementwise.  scale_atol covers
+    f32 accumulation-order noise on values that are small differences of O(max|want|) terms."""
     got = got.double(); want = want.double()
     err = (got - want).abs()
-    tol = atol + rtol * want.abs()
+    tol = atol + scale_atol * float(want.abs().max()) + rtol * want.abs()
     worst = float((err - tol).max())
     assert worst <= 0, "%s: max abs err %.3e (max |ref| %.3e), exceeds tol by %.3e" % (
         name, float(err.max()), float(want.abs().max()), worst)
@@ -71,12 +73,12 @@ def test_forward_every_stage_vs_oracle_and_golden(se3, model0, golden_dir):
     pool = _nchw(eng.debug_buffer("pool", n))
     _close("poolA", pool[:, :64], ref["poolA"], ACT_RTOL, 1e-5)
     cat = _nchw(eng.debug_buffer("q64", n))
-    _close("cat(a,b)", cat, ref["cat"], ACT_RTOL, 2e-5)
+    _close("cat(a,b)", cat, ref["cat"], ACT_RTOL, 0, 5e-6)
     feat = out["feature"].cpu()
-    _close("feature", feat, ref["feature"], ACT_RTOL, 5e-5)
+    _close("feature", feat, ref["feature"], ACT_RTOL, 0, 5e-6)
     head = _nchw(eng.debug_buffer("head", n))
-    _close("trans_conv2", head[:, :512], ref["trans_c2"], ACT_RTOL, 1e-4)
-    _close("rot_conv2", head[:, 512:], ref["rot_c2"], ACT_RTOL, 1e-4)
+    _close("trans_conv2", head[:, :512], ref["trans_c2"], ACT_RTOL, 0, 5e-6)
+    _close("rot_conv2", head[:, 512:], ref["rot_c2"], ACT_RTOL, 0, 5e-6)
     lg = eng.logits(n).cpu()
     _close("trans_logit", lg[:, :3], ref["trans_logit"], 0, NET_TOL)
     _close("rot_logit", lg[:, 3:], ref["rot_logit"], 0, NET_TOL)
@@ -85,8 +87,8 @@ def test_forward_every_stage_vs_oracle_and_golden(se3, model0, golden_dir):
     # and against what the reference's own code produced
     _close("trans vs golden", out["trans"].cpu(), torch.from_numpy(g["trans"]), 0, NET_TOL)
     _close("rot vs golden", out["rot"].cpu(), torch.from_numpy(g["rot"]), 0, NET_TOL)
-    _close("feature vs golden", feat[:, ::SUB, ::SUB, ::SUB], torch.from_numpy(g["feature"]), ACT_RTOL, 5e-5)
-    _close("trans_conv2 vs golden", head[:, :512][:, ::SUB, ::SUB, ::SUB], torch.from_numpy(g["act_trans_conv2"]), ACT_RTOL, 1e-4)
+    _close("feature vs golden", feat[:, ::SUB, ::SUB, ::SUB], torch.from_numpy(g["feature"]), ACT_RTOL, 0, 5e-6)
+    _close("trans_conv2 vs golden", head[:, :512][:, ::SUB, ::SUB, ::SUB], torch.from_numpy(g["act_trans_conv2"]), ACT_RTOL, 0, 5e-6)
     print("max |d(trans,rot)| = %.2e" % max(e1, e2))
 
 
