@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the se(3)-TrackNet hot path on MI355X.
+
+Metric (BASELINE.json): RGB-D pair inferences / s at 176x176.  A "step" is one pass of the hot path
+over one batch of synthetic pairs already resident in HBM:
+    se3tn_preprocess (crop + nearest-resize + depth offset + normalise, A and B)
+ -> se3tn_infer      (two-branch CNN, 5.527 GFLOP / pair, exact-f32 MFMA)  + pose update
+ -> (N>1) all-gather of the poses over RCCL.
+N=1 workload = BASELINE configs[1]: batch 64 pairs, random-init weights on the reference's
+state_dict surface (pretrained 003_cracker_box weights are not available offline).
+N>1: weak scaling, 64 pairs per GPU, weights broadcast once from rank 0 over RCCL.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--stage full|net]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR = 5527115776            # BASELINE.md section 3 (17 convs + 2 FC)
+CONV3_FLOP_PER_PAIR = 2 * (2763557888 - 194281472 - 3072)  # the ten 3x3 conv launches (no stem/FC)
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step")
+    ap.add_argument("--stage", default="full", choices=["full", "net"],
+                    help="full = preprocess + network + pose update (default); net = network + pose on "
+                         "pre-normalised NHWC pairs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print the per-launch time breakdown to stderr")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import se3tracknet_amd as se3
+    from oracle import se3_oracle as O  # weights generator + cpu_baseline leg only
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+    dist_mod = __import__("importlib").import_module("iros20-6d-pose-tracking_amd.dist")
+
+    nb = args.batch
+    eng = se3.Engine(local_rank, nb)
+    sd = O.make_state_dict(0) if rank == 0 else None
+    if world > 1:
+        dist_mod.load_weights_everywhere(eng, sd)       # C1: RCCL broadcast of the packed blob
+    else:
+        eng.load_state_dict(sd)
+    mean = np.array([110., 105., 100., 1000., 112., 104., 99., 1010.]); std = np.array([60., 58., 61., 300., 59., 60., 62., 310.])
+    eng.set_normalization(mean, std)
+    eng.set_normalizers(0.03, 5 * np.pi / 180)
+
+    # ---- synthetic inputs, resident in HBM (seeded per rank) -------------------------------
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    H, W = 480, 640
+    frames_rgb = torch.randint(0, 256, (nb, H, W, 3), generator=g, device=dev, dtype=torch.uint8)
+    frames_d = torch.randint(300, 1500, (nb, H, W), generator=g, device=dev, dtype=torch.int16)
+    rend_rgb = torch.randint(0, 256, (nb, 176, 176, 3), generator=g, device=dev, dtype=torch.uint8)
+    rend_d = torch.randint(600, 1000, (nb, 176, 176), generator=g, device=dev, dtype=torch.int16)
+    rng = np.random.default_rng(7 + rank)
+    poses = np.tile(np.eye(4), (nb, 1, 1))
+    poses[:, 0, 3] = rng.uniform(-0.15, 0.15, nb); poses[:, 1, 3] = rng.uniform(-0.1, 0.1, nb)
+    poses[:, 2, 3] = rng.uniform(0.6, 1.0, nb)
+    K = np.array([[1066.778, 0, 312.9869], [0, 1067.487, 241.3109], [0, 0, 1]])
+    cropsA, cropsB = [], []
+    for i in range(nb):
+        bb = se3.compute_bbox(poses[i], K, 250.0)
+        z = float(poses[i, 2, 3]) * 1000
+        cropsA.append(dict(rgb=rend_rgb[i], depth=rend_d[i], window=(0, 0, 176, 176), z_offset_mm=z, stats=0))
+        cropsB.append(dict(rgb=frames_rgb[i], depth=frames_d[i], window=se3.crop_window(bb), z_offset_mm=z, stats=1))
+    poseA = torch.from_numpy(poses.reshape(nb, 16)).to(dev)
+    poseB = torch.empty_like(poseA)
+    trans = torch.empty((nb, 3), device=dev); rot = torch.empty((nb, 3), device=dev)
+    inA, inB = eng.input_buffer_ptr(0), eng.input_buffer_ptr(1)
+    if args.stage == "net":
+        eng.preprocess(cropsA, inA); eng.preprocess(cropsB, inB)
+
+    def step():
+        if args.stage == "full":
+            eng.preprocess(cropsA, inA)
+            eng.preprocess(cropsB, inB)
+        eng.infer(inA, inB, nb, se3.NHWC, trans, rot, poseA, poseB)
+        if world > 1:
+            return dist_mod.gather_poses(poseB)      # C2
+        return poseB
+
+    for _ in range(args.warmup):
+        step()
+    slots = min(args.steps, 64)
+    eng.profile_enable(slots)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel family, from the HIP events of the timed region ----
+    conv_ms, tot_ms, nconv = [], [], 0
+    for s in range(slots):
+        c, nconv, t = eng.profile_read(s)
+        conv_ms.append(c); tot_ms.append(t)
+    conv_ms_avg = float(np.mean(conv_ms))
+    achieved = CONV3_FLOP_PER_PAIR * nb / (conv_ms_avg * 1e-3) / 1e12
+    layers = eng.profile_launches(slots - 1)
+    eng.profile_enable(0)
+    assert torch.isfinite(poseB).all()
+
+    if rank == 0:
+        value = world * nb * args.steps / dt
+        out = {
+            "metric": "RGB-D pair inferences/sec (176x176)", "value": round(value, 1), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch=%d synthetic 176x176 RGB-D pairs per GPU, random-init Se3TrackNet "
+                                   "(reference state_dict surface), stage=%s" % (nb, args.stage),
+                       "pairs_per_gpu": nb, "global_batch": world * nb, "stage": args.stage,
+                       "parallelism": "frame-sharded x%d, RCCL weight broadcast + pose all-gather" % world},
+            "tflops_total": round(value * FLOP_PER_PAIR / 1e12, 2),
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (10 launches/step, exact-f32 v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "conv_ms_per_step": round(conv_ms_avg, 4), "all_kernels_ms_per_step": round(float(np.mean(tot_ms)), 4),
+                         "flop_per_step": CONV3_FLOP_PER_PAIR * nb},
+            "layers_ms": {n: round(ms, 4) for n, ms in layers},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(O, sd, nb)
+        if args.layers:
+            for n, ms in layers:
+                print("%-32s %8.3f ms" % (n, ms), file=sys.stderr)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(O, sd, nb):
+    """The CPU oracle (torch-CPU fp32 restatement of the reference network + numpy pre/post) timed
+    on this box's host cores on a bounded sample (~10-20 s)."""
+    import numpy as np
+    import torch
+    from oracle import fixtures as Fx
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    A, B = Fx.net_inputs(3, nb)
+    O.forward(sd, A[:8], B[:8])  # warm-up
+    runs, t_net = 0, 0.0
+    while t_net < 8.0 and runs < 20:
+        t0 = time.perf_counter(); O.forward(sd, A, B); t_net += time.perf_counter() - t0; runs += 1
+    net_s_per_pair = t_net / (runs * nb)
+    # pre/post (numpy, single-threaded python as in the reference): 8 pairs
+    mean, std = Fx.mean_std(0)
+    rgb, depth = Fx.synthetic_frame(3); P = Fx.pose(3); rgbA, depthA = Fx.synthetic_render(103, 0.8)
+    t0 = time.perf_counter()
+    for _ in range(8):
+        bb = O.compute_bbox(P, Fx.K_YCB, 250.0, (1000, 1000, 1000))
+        rgbB, depthB = O.crop_bbox(rgb, depth, bb, (176, 176))
+        O.process_data(rgbA, depthA, P, rgbB, depthB, mean, std)
+        O.process_predict(P, np.zeros(3, np.float32), np.zeros(3, np.float32))
+    pp_s_per_pair = (time.perf_counter() - t0) / 8
+    return {"value": round(1.0 / (net_s_per_pair + pp_s_per_pair), 2), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "oracle (torch-CPU fp32, %d threads): %d x batch-%d network forwards (%.2f s) + 8 numpy "
+                      "pre/post-processing passes; network-only %.1f pairs/s" % (cores, runs, nb, t_net, 1.0 / net_s_per_pair)}
+
+
+if __name__ == "__main__":
+    main()

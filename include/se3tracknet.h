@@ -126,15 +126,16 @@ int se3tn_debug_buffer(se3tn_ctx* ctx, const char* name, const float** ptr, int3
 /* stream-ordered device-to-device copy (lets a ctypes host wrap the raw pointers above into its
  * own tensors without a second HIP binding) */
 int se3tn_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
-/* Timing hooks used by bench.py: time of the dominant kernel family (3x3 MFMA convolutions)
- * inside the LAST se3tn_infer, measured with hipEvents on `stream` when enabled (the events
- * are recorded around each conv launch; reading them synchronises). */
-int se3tn_profile_enable(se3tn_ctx* ctx, int on);
-int se3tn_profile_read(se3tn_ctx* ctx, float* conv_ms, int* conv_launches, float* total_ms);
-/* Per-launch breakdown of the last se3tn_infer: fills up to `cap` names / milliseconds, returns
- * the number of launches (>= 0) or an error (< 0 is impossible here: errors are > 0 hipError_t or
- * SE3TN_E_STATE). */
-int se3tn_profile_launches(se3tn_ctx* ctx, int cap, const char** names, float* ms);
+/* Timing hooks used by bench.py.  se3tn_profile_enable(ctx, slots) (slots <= 64, 0 = off) makes
+ * every following se3tn_infer record hipEvents around each of its launches on `stream`, into event
+ * set (call index % slots) -- no synchronisation is added to the timed loop.  Reading a slot
+ * synchronises on its last event.  conv_ms = time inside the dominant kernel family (the 3x3
+ * f32-MFMA convolutions, `conv_launches` launches), total_ms = all launches of that infer. */
+int se3tn_profile_enable(se3tn_ctx* ctx, int slots);
+int se3tn_profile_read(se3tn_ctx* ctx, int slot, float* conv_ms, int* conv_launches, float* total_ms);
+/* Per-launch breakdown of one slot: fills up to `cap` names / milliseconds, returns the number of
+ * launches (0 on error, see se3tn_last_error). */
+int se3tn_profile_launches(se3tn_ctx* ctx, int slot, int cap, const char** names, float* ms);
 
 #ifdef __cplusplus
 }

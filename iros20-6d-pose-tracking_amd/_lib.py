@@ -52,8 +52,9 @@ _SIGS = {
     "se3tn_debug_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "se3tn_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "se3tn_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
-    "se3tn_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
-    "se3tn_profile_launches": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
+    "se3tn_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_float)]),
+    "se3tn_profile_launches": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
 }
 
 _lib = None

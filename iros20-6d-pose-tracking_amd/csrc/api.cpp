@@ -27,7 +27,7 @@ static int hipfail(hipError_t e, const char* what) {
     if (_e != hipSuccess) return hipfail(_e, #x);  \
   } while (0)
 
-enum { MAX_LAUNCHES = 24 };
+enum { MAX_LAUNCHES = 24, MAX_SLOTS = 64 };
 
 struct se3tn_ctx {
   int device = -1, max_batch = 0;
@@ -48,9 +48,12 @@ struct se3tn_ctx {
   double tn = 0.03, rn = 5.0 * 3.14159265358979323846 / 180.0;
   // profiling
   bool prof = false;
-  hipEvent_t ev[MAX_LAUNCHES + 1];
-  bool ev_init = false;
+  int slots = 0;          // number of event sets (one per profiled se3tn_infer, used round-robin)
+  long long infer_count = 0;
+  hipEvent_t* ev = nullptr;  // points at evs[slot]
+  hipEvent_t evs[MAX_SLOTS][MAX_LAUNCHES + 1];
   int n_launch = 0;
+  int slot_launches[MAX_SLOTS];
   const char* names[MAX_LAUNCHES];
   bool is_conv[MAX_LAUNCHES];
 };
@@ -102,8 +105,8 @@ void se3tn_destroy(se3tn_ctx* c) {
                      c->head_t, c->logits, c->blob_owned};
     for (float* b : bufs)
       if (b) (void)hipFree(b);
-    if (c->ev_init)
-      for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (int s = 0; s < c->slots; ++s)
+      for (auto& e : c->evs[s]) (void)hipEventDestroy(e);
   }
   delete c;
 }
@@ -219,7 +222,12 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
   const float* W = c->blob;
   const BlobLayout& L = c->L;
   c->n_launch = 0;
-  if (c->prof) HIPCHK(hipEventRecord(c->ev[0], st));
+  int slot = 0;
+  if (c->prof) {
+    slot = (int)(c->infer_count++ % c->slots);
+    c->ev = c->evs[slot];
+    HIPCHK(hipEventRecord(c->ev[0], st));
+  }
 
   if (layout == SE3TN_NCHW) {
     HIPCHK(launch_nchw_to_nhwc4(A, c->inA, n, st));
@@ -263,6 +271,7 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
 
   HIPCHK(launch_tail(c->head, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st));
   HIPCHK((hipError_t)prof_mark(c, st, "tail avgpool+fc+tanh+pose", false));
+  if (c->prof) c->slot_launches[slot] = c->n_launch;
   return SE3TN_OK;
 }
 
@@ -295,25 +304,30 @@ int se3tn_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
   return SE3TN_OK;
 }
 
-int se3tn_profile_enable(se3tn_ctx* c, int on) {
-  if (!c || c->device < 0) return fail(SE3TN_E_ARG, "se3tn_profile_enable: no device context");
-  if (on && !c->ev_init) {
-    for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
-    c->ev_init = true;
+int se3tn_profile_enable(se3tn_ctx* c, int slots) {
+  if (!c || c->device < 0 || slots < 0 || slots > MAX_SLOTS) return fail(SE3TN_E_ARG, "se3tn_profile_enable: bad argument");
+  for (int s = c->slots; s < slots; ++s) {
+    for (auto& e : c->evs[s]) HIPCHK(hipEventCreate(&e));
+    c->slot_launches[s] = 0;
+    c->slots = s + 1;
   }
-  c->prof = on != 0;
-  c->n_launch = 0;
+  c->prof = slots > 0;
+  c->infer_count = 0;
+  for (int s = 0; s < c->slots; ++s) c->slot_launches[s] = 0;
   return SE3TN_OK;
 }
 
-int se3tn_profile_read(se3tn_ctx* c, float* conv_ms, int* conv_launches, float* total_ms) {
-  if (!c || !c->prof || c->n_launch == 0) return fail(SE3TN_E_STATE, "se3tn_profile_read: nothing recorded");
-  HIPCHK(hipEventSynchronize(c->ev[c->n_launch]));
+int se3tn_profile_read(se3tn_ctx* c, int slot, float* conv_ms, int* conv_launches, float* total_ms) {
+  if (!c || slot < 0 || slot >= c->slots || c->slot_launches[slot] == 0)
+    return fail(SE3TN_E_STATE, "se3tn_profile_read: nothing recorded in this slot");
+  const int nl = c->slot_launches[slot];
+  hipEvent_t* ev = c->evs[slot];
+  HIPCHK(hipEventSynchronize(ev[nl]));
   float conv = 0.f, tot = 0.f;
   int nconv = 0;
-  for (int i = 0; i < c->n_launch; ++i) {
+  for (int i = 0; i < nl; ++i) {
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+    HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
     tot += ms;
     if (c->is_conv[i]) { conv += ms; ++nconv; }
   }
@@ -323,13 +337,18 @@ int se3tn_profile_read(se3tn_ctx* c, float* conv_ms, int* conv_launches, float* 
   return SE3TN_OK;
 }
 
-int se3tn_profile_launches(se3tn_ctx* c, int cap, const char** names, float* ms) {
-  if (!c || !c->prof || c->n_launch == 0) return fail(SE3TN_E_STATE, "se3tn_profile_launches: nothing recorded");
-  HIPCHK(hipEventSynchronize(c->ev[c->n_launch]));
-  int k = c->n_launch < cap ? c->n_launch : cap;
+int se3tn_profile_launches(se3tn_ctx* c, int slot, int cap, const char** names, float* ms) {
+  if (!c || slot < 0 || slot >= c->slots || c->slot_launches[slot] == 0) {
+    fail(SE3TN_E_STATE, "se3tn_profile_launches: nothing recorded in this slot");
+    return 0;
+  }
+  const int nl = c->slot_launches[slot];
+  hipEvent_t* ev = c->evs[slot];
+  if (hipEventSynchronize(ev[nl]) != hipSuccess) return 0;
+  int k = nl < cap ? nl : cap;
   for (int i = 0; i < k; ++i) {
     if (names) names[i] = c->names[i];
-    if (ms) HIPCHK(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    if (ms && hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) return 0;
   }
   return k;
 }

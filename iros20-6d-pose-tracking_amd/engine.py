@@ -138,20 +138,22 @@ class Engine:
         return out
 
     # ---- profiling -------------------------------------------------------------------------
-    def profile_enable(self, on=True):
-        check(self.lib.se3tn_profile_enable(self._h, 1 if on else 0), "se3tn_profile_enable")
+    def profile_enable(self, slots=1):
+        check(self.lib.se3tn_profile_enable(self._h, int(slots)), "se3tn_profile_enable")
 
-    def profile_read(self):
+    def profile_read(self, slot=0):
+        """(ms inside the conv3x3 MFMA family, number of such launches, ms of all launches)"""
         conv = C.c_float(); nl = C.c_int(); tot = C.c_float()
-        check(self.lib.se3tn_profile_read(self._h, C.byref(conv), C.byref(nl), C.byref(tot)), "se3tn_profile_read")
+        check(self.lib.se3tn_profile_read(self._h, slot, C.byref(conv), C.byref(nl), C.byref(tot)),
+              "se3tn_profile_read")
         return conv.value, nl.value, tot.value
 
-    def profile_launches(self):
+    def profile_launches(self, slot=0):
         names = (C.c_char_p * 32)()
         ms = (C.c_float * 32)()
-        k = self.lib.se3tn_profile_launches(self._h, 32, names, ms)
-        if k < 0:
-            check(k, "se3tn_profile_launches")
+        k = self.lib.se3tn_profile_launches(self._h, slot, 32, names, ms)
+        if k <= 0:
+            raise Se3tnError("se3tn_profile_launches: " + self.lib.se3tn_last_error().decode())
         return [(names[i].decode(), ms[i]) for i in range(k)]
 
 
