@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libse3tracknet.so")
+# SE3TN_LIB: developer override used for within-session A/B of kernel variants
+LIB_PATH = os.environ.get("SE3TN_LIB") or os.path.join(_HERE, "libse3tracknet.so")
 
 NCHW, NHWC = 0, 1
 RES = 176

@@ -43,6 +43,7 @@ struct se3tn_ctx {
   float *ab = nullptr, *ab_t = nullptr;         // [mb,22,22,256]
   float *head = nullptr, *head_t = nullptr;     // [mb,11,11,1024]
   float* logits = nullptr;                      // [mb,6]
+  float* zeros = nullptr;                       // 256 B of zeros
   double mean[8], stdv[8];
   bool have_norm = false;
   double tn = 0.03, rn = 5.0 * 3.14159265358979323846 / 180.0;
@@ -88,11 +89,13 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
         {&c->t64, mb * S2 * S2 * 128},   {&c->q64, mb * S2 * S2 * 128},
         {&c->ab, mb * S3 * S3 * 256},    {&c->ab_t, mb * S3 * S3 * 256},
         {&c->head, mb * S4 * S4 * 1024}, {&c->head_t, mb * S4 * S4 * 1024},
-        {&c->logits, mb * 6}};
+        {&c->logits, mb * 6},            {&c->zeros, 64}};
     for (auto& b : bufs) {
       e = hipMalloc((void**)b.p, b.words * sizeof(float));
       if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(workspace)"); }
     }
+    e = hipMemset(c->zeros, 0, 64 * sizeof(float));
+    if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMemset(zeros)"); }
   }
   *out = c;
   return SE3TN_OK;
@@ -102,7 +105,7 @@ void se3tn_destroy(se3tn_ctx* c) {
   if (!c) return;
   if (c->device >= 0) {
     float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
-                     c->head_t, c->logits, c->blob_owned};
+                     c->head_t, c->logits, c->zeros, c->blob_owned};
     for (float* b : bufs)
       if (b) (void)hipFree(b);
     for (int s = 0; s < c->slots; ++s)
@@ -245,7 +248,7 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
                   float* out, int out_ld, int out_gs, int hin, int stride, int epi, const char* name) -> int {
     const Conv3& s = conv_specs()[id];
     ConvArgs a{};
-    a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id]; a.res = res; a.out = out;
+    a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id]; a.res = res; a.out = out; a.zeros = c->zeros;
     a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
     a.H = hin; a.W = hin; a.Ho = (hin - 1) / stride + 1; a.Wo = a.Ho;
     a.M = n * a.Ho * a.Wo;

@@ -100,27 +100,59 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     rowmask[j] = mask;
   }
 
-  float4 ra[PR], rb[WR];
-  auto load_tile = [&](int ch, int tap) {
-    const int r = tap / 3, s = tap - r * 3;
-    const int toff = (r * a.W + s) * a.in_ld + ch * 32;
-#pragma unroll
-    for (int j = 0; j < PR; ++j) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((rowmask[j] >> tap) & 1u) v = *reinterpret_cast<const float4*>(in + rowoff[j] + toff);
-      ra[j] = v;
-    }
-    const float* wt = wgt + ((size_t)(ch * 9 + tap) * (a.tiles_n * BN) + n0) * 32 + tid * 4;
-#pragma unroll
-    for (int j = 0; j < WR; ++j) rb[j] = *reinterpret_cast<const float4*>(wt + j * 1024);
-  };
-  auto store_tile = [&](int buf) {
-    float* dst = smem + buf * BUF + r0 * LDK + c4 * 4;
-#pragma unroll
-    for (int j = 0; j < PR; ++j) *reinterpret_cast<float4*>(dst + (32 * j) * LDK) = ra[j];
-#pragma unroll
-    for (int j = 0; j < WR; ++j) *reinterpret_cast<float4*>(dst + (BM + 32 * j) * LDK) = rb[j];
-  };
+  // Staging registers and the three phases of a K-step are written out as macros (not lambdas /
+  // runtime-indexed arrays) so that the prefetched tile provably stays in VGPRs.
+  static_assert(PR == 4 && (WR == 2 || WR == 4), "staging code below is written for BM=128, BN=64|128");
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // named scalars: hipcc keeps arrays pinned by a
+                                                   // scheduling barrier in scratch memory
+  rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define LOAD_PIX(J, DST)                                                                            \
+  DST = *reinterpret_cast<const float4*>(((rowmask[J] >> tap_) & 1u) ? in + rowoff[J] + toff_ : a.zeros);
+#define LOAD_TILE(CH, TAP)                                                                         \
+  {                                                                                                \
+    const int tap_ = (TAP);                                                                        \
+    const int r_ = tap_ / 3, s_ = tap_ - r_ * 3;                                                   \
+    const int toff_ = (r_ * a.W + s_) * a.in_ld + (CH) * 32;                                       \
+    /* out-of-image taps read a 16-byte zero line instead of branching around the load */         \
+    LOAD_PIX(0, ra0) LOAD_PIX(1, ra1) LOAD_PIX(2, ra2) LOAD_PIX(3, ra3)                            \
+    const float* wt_ = wgt + ((size_t)((CH) * 9 + tap_) * (a.tiles_n * BN) + n0) * 32 + tid * 4;   \
+    rb0 = *reinterpret_cast<const float4*>(wt_);                                                   \
+    rb1 = *reinterpret_cast<const float4*>(wt_ + 1024);                                            \
+    if constexpr (WR == 4) {                                                                       \
+      rb2 = *reinterpret_cast<const float4*>(wt_ + 2048);                                          \
+      rb3 = *reinterpret_cast<const float4*>(wt_ + 3072);                                          \
+    }                                                                                              \
+  }
+#define STORE_TILE(BUFI)                                                                           \
+  {                                                                                                \
+    float* dst_ = smem + (BUFI) * BUF + r0 * LDK + c4 * 4;                                         \
+    *reinterpret_cast<float4*>(dst_) = ra0;                                                        \
+    *reinterpret_cast<float4*>(dst_ + 32 * LDK) = ra1;                                             \
+    *reinterpret_cast<float4*>(dst_ + 64 * LDK) = ra2;                                             \
+    *reinterpret_cast<float4*>(dst_ + 96 * LDK) = ra3;                                             \
+    *reinterpret_cast<float4*>(dst_ + BM * LDK) = rb0;                                             \
+    *reinterpret_cast<float4*>(dst_ + (BM + 32) * LDK) = rb1;                                      \
+    if constexpr (WR == 4) {                                                                       \
+      *reinterpret_cast<float4*>(dst_ + (BM + 64) * LDK) = rb2;                                    \
+      *reinterpret_cast<float4*>(dst_ + (BM + 96) * LDK) = rb3;                                    \
+    }                                                                                              \
+  }
+#define MMA_GROUP(KG)                                                                              \
+  {                                                                                                \
+    float4 pv_[PT], wv_[CT];                                                                       \
+    _Pragma("unroll") for (int i = 0; i < PT; ++i)                                                 \
+        pv_[i] = *reinterpret_cast<const float4*>(pP + i * 32 * LDK + (KG) * 8);                   \
+    _Pragma("unroll") for (int j = 0; j < CT; ++j)                                                 \
+        wv_[j] = *reinterpret_cast<const float4*>(pW + j * 32 * LDK + (KG) * 8);                   \
+    _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i)  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[j].x, pv_[i].x, acc[i][j], 0, 0, 0);  \
+    _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i)  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[j].y, pv_[i].y, acc[i][j], 0, 0, 0);  \
+    _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i)  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[j].z, pv_[i].z, acc[i][j], 0, 0, 0);  \
+    _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i)  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[j].w, pv_[i].w, acc[i][j], 0, 0, 0);  \
+  }
 
   f32x16 acc[PT][CT];
 #pragma unroll
@@ -130,43 +162,48 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  load_tile(0, 0);
-  store_tile(0);
+  LOAD_TILE(0, 0)
+  STORE_TILE(0)
   __syncthreads();
 
   int ch = 0, tap = 0;
-  for (int kt = 0; kt < KT; ++kt) {
+  for (int kt = 0; kt < KT - 1; ++kt) {
     const int buf = kt & 1;
     if (++tap == 9) { tap = 0; ++ch; }
-    if (kt + 1 < KT) load_tile(ch, tap);
-
+    LOAD_TILE(ch, tap)
+    // keep all global loads of the next tile in flight under this tile's MFMAs: without the pin
+    // hipcc sinks the weight loads to just before their ds_write and eats the L2 latency
+    __builtin_amdgcn_sched_barrier(0);
     const float* pP = smem + buf * BUF + (wm * PT * 32 + l31) * LDK + hh * 4;
     const float* pW = smem + buf * BUF + (BM + wn * CT * 32 + l31) * LDK + hh * 4;
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      float pv[PT][4], wv[CT][4];
-#pragma unroll
-      for (int i = 0; i < PT; ++i) {
-        const float4 t = *reinterpret_cast<const float4*>(pP + i * 32 * LDK + kg * 8);
-        pv[i][0] = t.x; pv[i][1] = t.y; pv[i][2] = t.z; pv[i][3] = t.w;
-      }
-#pragma unroll
-      for (int j = 0; j < CT; ++j) {
-        const float4 t = *reinterpret_cast<const float4*>(pW + j * 32 * LDK + kg * 8);
-        wv[j][0] = t.x; wv[j][1] = t.y; wv[j][2] = t.z; wv[j][3] = t.w;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int j = 0; j < CT; ++j)
-#pragma unroll
-          for (int i = 0; i < PT; ++i)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][e], pv[i][e], acc[i][j], 0, 0, 0);
-    }
-
-    if (kt + 1 < KT) store_tile(buf ^ 1);
+    MMA_GROUP(0)
+    MMA_GROUP(1)
+    // the other LDS buffer has been free since the barrier that ended the previous K-step: write
+    // the prefetched tile half-way, so the ds_writes retire under the remaining MFMAs
+#ifdef SE3TN_PIN_STORE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    STORE_TILE(buf ^ 1)
+#ifdef SE3TN_PIN_STORE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    MMA_GROUP(2)
+    MMA_GROUP(3)
     __syncthreads();
   }
+  {
+    const int buf = (KT - 1) & 1;
+    const float* pP = smem + buf * BUF + (wm * PT * 32 + l31) * LDK + hh * 4;
+    const float* pW = smem + buf * BUF + (BM + wn * CT * 32 + l31) * LDK + hh * 4;
+    MMA_GROUP(0)
+    MMA_GROUP(1)
+    MMA_GROUP(2)
+    MMA_GROUP(3)
+  }
+#undef LOAD_TILE
+#undef LOAD_PIX
+#undef STORE_TILE
+#undef MMA_GROUP
 
   // ---- epilogue: lane holds pixel (l31) x couts {8q + 4hh + 0..3}, q = 0..3, per 32x32 tile ----
   const float* __restrict__ bias = a.bias + (size_t)g * a.bias_gs;

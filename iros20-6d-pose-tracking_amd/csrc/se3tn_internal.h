@@ -88,6 +88,7 @@ struct ConvArgs {
   const float* w;     // packed panels of group 0
   const float* bias;  // folded bias of group 0
   const float* res;   // residual (geometry of out) or nullptr
+  const float* zeros; // >= 16 bytes of zeros (source of out-of-image taps)
   float* out;
   int in_ld, res_ld, out_ld;
   int H, W, Ho, Wo;   // input / output spatial size
