@@ -173,9 +173,20 @@ def cpu_baseline(O, sd, nb):
     import numpy as np
     import torch
     from oracle import fixtures as Fx
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     A, B = Fx.net_inputs(3, nb)
+    # oneDNN collapses when over-subscribed (256 threads: 4 pairs/s on the 2x64-core EPYC box):
+    # sweep the thread count on a small batch and time the sample with the best one
+    best, cores = None, ncpu
+    for th in sorted({max(1, ncpu // 8), max(1, ncpu // 4), max(1, ncpu // 2), ncpu}):
+        torch.set_num_threads(th)
+        O.forward(sd, A[:4], B[:4])
+        t0 = time.perf_counter(); O.forward(sd, A[:16], B[:16]); dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, th
+        if dt > 6.0:
+            break
+    torch.set_num_threads(cores)
     O.forward(sd, A[:8], B[:8])  # warm-up
     runs, t_net = 0, 0.0
     while t_net < 8.0 and runs < 20:
@@ -192,8 +203,9 @@ def cpu_baseline(O, sd, nb):
         O.process_predict(P, np.zeros(3, np.float32), np.zeros(3, np.float32))
     pp_s_per_pair = (time.perf_counter() - t0) / 8
     return {"value": round(1.0 / (net_s_per_pair + pp_s_per_pair), 2), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "oracle (torch-CPU fp32, %d threads): %d x batch-%d network forwards (%.2f s) + 8 numpy "
-                      "pre/post-processing passes; network-only %.1f pairs/s" % (cores, runs, nb, t_net, 1.0 / net_s_per_pair)}
+            "sample": "oracle (torch-CPU fp32, best of a thread sweep = %d of %d logical CPUs): %d x batch-%d network forwards "
+                      "(%.2f s) + 8 numpy pre/post-processing passes; network-only %.1f pairs/s"
+                      % (cores, ncpu, runs, nb, t_net, 1.0 / net_s_per_pair)}
 
 
 if __name__ == "__main__":

@@ -1,0 +1,69 @@
+"""CPU, world_size 2, gloo: the multi-GPU plumbing of the path (frame sharding, weight-blob
+broadcast C1, pose all-gather C2) -- the same code bench.py runs over RCCL."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    D = importlib.import_module("iros20-6d-pose-tracking_amd.dist")
+    se3 = importlib.import_module("se3tracknet_amd")
+    from oracle import se3_oracle as O
+    try:
+        # C1: rank 0 folds+packs (host-only context), broadcast, byte-identical everywhere
+        eng = se3.Engine(device=-1, max_batch=1)
+        blob = eng.pack_state_dict(O.make_state_dict(0)) if rank == 0 else None
+        buf = D.broadcast_blob(blob, eng.packed_bytes(), "cpu")
+        ref = torch.tensor([int(buf.to(torch.int64).sum())])
+        dist.broadcast(ref, 0)
+        assert int(buf.to(torch.int64).sum()) == int(ref) and buf.numel() == eng.packed_bytes()
+        # sharding covers [0, n) exactly once
+        for n in (512, 7, 64):
+            lo, hi = D.shard_range(n, rank, world)
+            spans = [None] * world
+            dist.all_gather_object(spans, (lo, hi))
+            assert spans[0][0] == 0 and spans[-1][1] == n and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        # C2: pose all-gather keeps rank order
+        local = torch.full((4, 16), float(rank), dtype=torch.float64)
+        allp = D.gather_poses(local)
+        assert allp.shape == (4 * world, 16)
+        assert all(float(allp[4 * r, 0]) == r for r in range(world))
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_plumbing():
+    world = 2
+    port = 29000 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_shard_range_properties():
+    D = importlib.import_module("iros20-6d-pose-tracking_amd.dist")
+    for n in (0, 1, 63, 64, 512, 1000):
+        for w in (1, 2, 4, 8):
+            spans = [D.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sum(sizes) == n
