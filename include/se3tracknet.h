@@ -119,9 +119,10 @@ int se3tn_pose_update_host(const double poseA[16], const float trans[3], const f
 
 /* ---- introspection for tests / profiling --------------------------------------------------- */
 /* Device pointer + geometry of an internal NHWC activation buffer after se3tn_infer.
- * names: "stem" [n,88,88,128] "pool" "t64" "q64" [n,44,44,128] (channels 0-63 branch A, 64-127
- * branch B), "ab" "ab_t" [n,22,22,256], "head" "head_t" [n,11,11,1024] (0-511 trans, 512-1023
- * rot).  dims = {H, W, C}. */
+ * names: "inA" "inB" [n,176,176,4], "stem" [n,88,88,128]; the conv activations carry a one-pixel
+ * zero border: "pool" "t64" "q64" [n,46,46,128] (channels 0-63 branch A, 64-127 branch B),
+ * "ab" "ab_t" [n,24,24,256], "head" "head_t" [n,13,13,1024] (0-511 trans, 512-1023 rot).
+ * dims = {H, W, C} as stored (borders included). */
 int se3tn_debug_buffer(se3tn_ctx* ctx, const char* name, const float** ptr, int32_t dims[3]);
 /* stream-ordered device-to-device copy (lets a ctypes host wrap the raw pointers above into its
  * own tensors without a second HIP binding) */

@@ -39,11 +39,11 @@ struct se3tn_ctx {
   // activations (NHWC float32)
   float *inA = nullptr, *inB = nullptr;         // [mb,176,176,4]
   float* stem = nullptr;                        // [mb,88,88,128]
-  float *pool = nullptr, *t64 = nullptr, *q64 = nullptr;  // [mb,44,44,128]
-  float *ab = nullptr, *ab_t = nullptr;         // [mb,22,22,256]
-  float *head = nullptr, *head_t = nullptr;     // [mb,11,11,1024]
+  // zero-bordered conv activations (se3tn_internal.h: ConvArgs)
+  float *pool = nullptr, *t64 = nullptr, *q64 = nullptr;  // [mb,46,46,128]
+  float *ab = nullptr, *ab_t = nullptr;         // [mb,24,24,256]
+  float *head = nullptr, *head_t = nullptr;     // [mb,13,13,1024]
   float* logits = nullptr;                      // [mb,6]
-  float* zeros = nullptr;                       // 256 B of zeros
   double mean[8], stdv[8];
   bool have_norm = false;
   double tn = 0.03, rn = 5.0 * 3.14159265358979323846 / 180.0;
@@ -83,19 +83,23 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
     e = hipSetDevice(device);
     if (e != hipSuccess) { delete c; return hipfail(e, "hipSetDevice"); }
     const size_t mb = (size_t)max_batch;
-    struct { float** p; size_t words; } bufs[] = {
-        {&c->inA, mb * RES * RES * 4},   {&c->inB, mb * RES * RES * 4},
-        {&c->stem, mb * S1 * S1 * 128},  {&c->pool, mb * S2 * S2 * 128},
-        {&c->t64, mb * S2 * S2 * 128},   {&c->q64, mb * S2 * S2 * 128},
-        {&c->ab, mb * S3 * S3 * 256},    {&c->ab_t, mb * S3 * S3 * 256},
-        {&c->head, mb * S4 * S4 * 1024}, {&c->head_t, mb * S4 * S4 * 1024},
-        {&c->logits, mb * 6},            {&c->zeros, 64}};
+    auto padded = [&](int s, int ch) { return (mb * (s + 2) * (s + 2) + PAD_SLACK_PX) * ch; };
+    struct { float** p; size_t words; bool zero; } bufs[] = {
+        {&c->inA, mb * RES * RES * 4, false},  {&c->inB, mb * RES * RES * 4, false},
+        {&c->stem, mb * S1 * S1 * 128, false}, {&c->pool, padded(S2, 128), true},
+        {&c->t64, padded(S2, 128), true},      {&c->q64, padded(S2, 128), true},
+        {&c->ab, padded(S3, 256), true},       {&c->ab_t, padded(S3, 256), true},
+        {&c->head, padded(S4, 1024), true},    {&c->head_t, padded(S4, 1024), true},
+        {&c->logits, mb * 6, true}};
     for (auto& b : bufs) {
       e = hipMalloc((void**)b.p, b.words * sizeof(float));
       if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(workspace)"); }
+      // the one-pixel borders are written here once and never again (kernels store interiors only)
+      if (b.zero) e = hipMemset(*b.p, 0, b.words * sizeof(float));
+      if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMemset(workspace)"); }
     }
-    e = hipMemset(c->zeros, 0, 64 * sizeof(float));
-    if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMemset(zeros)"); }
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipDeviceSynchronize"); }
   }
   *out = c;
   return SE3TN_OK;
@@ -105,7 +109,7 @@ void se3tn_destroy(se3tn_ctx* c) {
   if (!c) return;
   if (c->device >= 0) {
     float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
-                     c->head_t, c->logits, c->zeros, c->blob_owned};
+                     c->head_t, c->logits, c->blob_owned};
     for (float* b : bufs)
       if (b) (void)hipFree(b);
     for (int s = 0; s < c->slots; ++s)
@@ -248,7 +252,7 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
                   float* out, int out_ld, int out_gs, int hin, int stride, int epi, const char* name) -> int {
     const Conv3& s = conv_specs()[id];
     ConvArgs a{};
-    a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id]; a.res = res; a.out = out; a.zeros = c->zeros;
+    a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id]; a.res = res; a.out = out;
     a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
     a.H = hin; a.W = hin; a.Ho = (hin - 1) / stride + 1; a.Wo = a.Ho;
     a.M = n * a.Ho * a.Wo;
@@ -280,7 +284,7 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
 
 int se3tn_get_feature(se3tn_ctx* c, int n, float* feature_nchw, void* stream) {
   if (!c || c->device < 0 || !feature_nchw || n < 1 || n > c->max_batch) return fail(SE3TN_E_ARG, "se3tn_get_feature: bad argument");
-  HIPCHK(launch_nhwc_to_nchw(c->ab, feature_nchw, n, S3 * S3, 256, (hipStream_t)stream));
+  HIPCHK(launch_padded_nhwc_to_nchw(c->ab, feature_nchw, n, S3, S3, 256, (hipStream_t)stream));
   return SE3TN_OK;
 }
 
@@ -290,9 +294,10 @@ int se3tn_debug_buffer(se3tn_ctx* c, const char* name, const float** ptr, int32_
   if (!c || !name || !ptr || !dims) return fail(SE3TN_E_ARG, "se3tn_debug_buffer: bad argument");
   struct { const char* n; const float* p; int h, w, ch; } t[] = {
       {"inA", c->inA, RES, RES, 4},      {"inB", c->inB, RES, RES, 4},     {"stem", c->stem, S1, S1, 128},
-      {"pool", c->pool, S2, S2, 128},    {"t64", c->t64, S2, S2, 128},     {"q64", c->q64, S2, S2, 128},
-      {"ab", c->ab, S3, S3, 256},        {"ab_t", c->ab_t, S3, S3, 256},   {"head", c->head, S4, S4, 1024},
-      {"head_t", c->head_t, S4, S4, 1024}};
+      {"pool", c->pool, S2 + 2, S2 + 2, 128},    {"t64", c->t64, S2 + 2, S2 + 2, 128},
+      {"q64", c->q64, S2 + 2, S2 + 2, 128},      {"ab", c->ab, S3 + 2, S3 + 2, 256},
+      {"ab_t", c->ab_t, S3 + 2, S3 + 2, 256},    {"head", c->head, S4 + 2, S4 + 2, 1024},
+      {"head_t", c->head_t, S4 + 2, S4 + 2, 1024}};
   for (auto& e : t)
     if (std::strcmp(e.n, name) == 0) {
       *ptr = e.p; dims[0] = e.h; dims[1] = e.w; dims[2] = e.ch;

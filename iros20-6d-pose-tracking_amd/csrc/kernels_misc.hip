@@ -5,7 +5,7 @@
 //   tail         AdaptiveAvgPool2d(1) + Linear(512,3) + Tanh for both heads
 //                (se3_tracknet.py:72-73,77-78,100-109) + TrackDataset.processPredict
 //                (datasets.py:159-175): t_B = trans*tn + t_A, R_B = Rodrigues(rot*rn) . R_A
-//   nhwc_to_nchw  output['feature'] in the reference's layout
+//   padded_nhwc_to_nchw  output['feature'] in the reference's layout
 #include "se3tn_internal.h"
 
 namespace se3tn {
@@ -74,8 +74,9 @@ hipError_t launch_preprocess(const CropArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tail: one 256-thread workgroup per pair.  head = [n,11,11,1024] (trans 0-511 | rot 512-1023).
-// Thread t averages channels 4t..4t+3 over the 121 pixels (coalesced 4 KB rows), multiplies by
+// Tail: one 256-thread workgroup per pair.  head = zero-bordered [n,13,13,1024] (trans 0-511 | rot
+// 512-1023): summing all 169 rows equals summing the 121 interior pixels.
+// Thread t averages channels 4t..4t+3 (coalesced 4 KB rows), multiplies by
 // its 3x4 slice of the head's FC matrix; wave-shuffle + LDS reduction over the head's 128 threads.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -92,10 +93,11 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ hea
   __shared__ float part[4][3];
   __shared__ float outv[6];
   const int n = blockIdx.x, t = threadIdx.x;
-  const float* src = head + (size_t)n * (S4 * S4) * 1024 + t * 4;
+  constexpr int PP = (S4 + 2) * (S4 + 2);
+  const float* src = head + (size_t)n * PP * 1024 + t * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 11
-  for (int p = 0; p < S4 * S4; ++p) {
+#pragma unroll 13
+  for (int p = 0; p < PP; ++p) {
     const float4 v = *reinterpret_cast<const float4*>(src + (size_t)p * 1024);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
@@ -164,19 +166,20 @@ hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, 
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in,
-                                                            float* __restrict__ out, int hw, int c,
-                                                            int total) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;  // output index (n, c, p)
+__global__ __launch_bounds__(256) void padded_nhwc_to_nchw_kernel(const float* __restrict__ in,
+                                                                   float* __restrict__ out, int h, int w,
+                                                                   int c, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // output index (n, c, y, x)
   if (idx >= total) return;
-  const int p = idx % hw, t = idx / hw;
-  const int ch = t % c, n = t / c;
-  out[idx] = in[((size_t)n * hw + p) * c + ch];
+  const int x = idx % w, t1 = idx / w;
+  const int y = t1 % h, t2 = t1 / h;
+  const int ch = t2 % c, n = t2 / c;
+  out[idx] = in[((size_t)(n * (h + 2) + y + 1) * (w + 2) + x + 1) * c + ch];
 }
 
-hipError_t launch_nhwc_to_nchw(const float* in, float* out, int n, int hw, int c, hipStream_t st) {
-  const int total = n * hw * c;
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, hw, c, total);
+hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, hipStream_t st) {
+  const int total = n * h * w * c;
+  hipLaunchKernelGGL(padded_nhwc_to_nchw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, h, w, c, total);
   return hipGetLastError();
 }
 

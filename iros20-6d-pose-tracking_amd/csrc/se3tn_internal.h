@@ -83,15 +83,18 @@ inline BlobLayout blob_layout() {
 // ---------------------------------------------------------------------------------------------
 // kernel argument blocks
 // ---------------------------------------------------------------------------------------------
+// All conv activations are NHWC with a one-pixel zero border: a tensor of interior size H x W is
+// stored as [n][H+2][W+2][ld] (+ PAD_SLACK_PX pixels of slack after the last image, the slab DMA
+// rounds its run up to 8 pixels).
+constexpr int PAD_SLACK_PX = 8;
 struct ConvArgs {
-  const float* in;    // NHWC, `in_ld` floats per pixel; channel offset already applied
+  const float* in;    // padded NHWC, `in_ld` floats per pixel; channel offset already applied
   const float* w;     // packed panels of group 0
   const float* bias;  // folded bias of group 0
   const float* res;   // residual (geometry of out) or nullptr
-  const float* zeros; // >= 16 bytes of zeros (source of out-of-image taps)
-  float* out;
+  float* out;         // padded NHWC
   int in_ld, res_ld, out_ld;
-  int H, W, Ho, Wo;   // input / output spatial size
+  int H, W, Ho, Wo;   // input / output INTERIOR spatial size
   int M;              // n * Ho * Wo  (GEMM rows = output pixels)
   int tiles_n;        // Cout / BN
   int groups;         // independent convolutions in this launch
@@ -118,7 +121,8 @@ hipError_t launch_conv3x3(const ConvArgs& a, int cin, int cout, int stride, int 
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,
                        double rn, int n, hipStream_t st);
-hipError_t launch_nhwc_to_nchw(const float* in, float* out, int n, int hw, int c, hipStream_t st);
+// padded [n,h+2,w+2,c] NHWC interior -> [n,c,h,w]
+hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, hipStream_t st);
 
 // host-side packer (weights.cpp)
 struct HostTensor {

@@ -135,8 +135,9 @@ hipError_t launch_stem(const float* inA, const float* inB, const float* w, const
   return hipGetLastError();
 }
 
-// MaxPool2d(kernel 3, stride 2, padding 1) on [n,88,88,128] -> [n,44,44,128]; padding is -inf
-// (never wins), one thread per (output pixel, 4 channels).
+// MaxPool2d(kernel 3, stride 2, padding 1) on [n,88,88,128] -> the interior of the zero-bordered
+// [n,46,46,128] tensor the 64-channel convs read; the pool's own padding is -inf (never wins), so
+// its input keeps explicit bounds.  One thread per (output pixel, 4 channels).
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ in,
                                                             float* __restrict__ out, int total) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
       m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
     }
   }
-  *reinterpret_cast<float4*>(out + (size_t)pix * 128 + c4 * 4) = m;
+  *reinterpret_cast<float4*>(out + ((size_t)(n * (S2 + 2) + po + 1) * (S2 + 2) + qo + 1) * 128 + c4 * 4) = m;
 }
 
 hipError_t launch_maxpool(const float* in, float* out, int n, hipStream_t st) {
