@@ -87,10 +87,12 @@ typedef struct se3tn_crop {
   int32_t _pad;
 } se3tn_crop;
 /* `crops` is a HOST array of n descriptors (copied into kernel arguments, no sync);
- * out_nhwc: device float32 [n,176,176,4]. */
+ * out_nhwc: device float32 [n,176,176,4] -- or one of the context's own input buffers
+ * (se3tn_input_buffer), which are stored zero-bordered and consumed in place by se3tn_infer. */
 int se3tn_preprocess(se3tn_ctx* ctx, const se3tn_crop* crops, int n, float* out_nhwc,
                      void* stream);
-/* the context's own NHWC input buffers ([max_batch,176,176,4] float32), which = 0 (A) / 1 (B) */
+/* the context's own input buffers, which = 0 (A) / 1 (B).  Opaque layout ([max_batch,182,182,4],
+ * 3-pixel zero border): only pass them to se3tn_preprocess (as out) and se3tn_infer (as A / B). */
 float* se3tn_input_buffer(se3tn_ctx* ctx, int which);
 
 /* ---- the network + pose update ------------------------------------------------------------ */
@@ -119,7 +121,7 @@ int se3tn_pose_update_host(const double poseA[16], const float trans[3], const f
 
 /* ---- introspection for tests / profiling --------------------------------------------------- */
 /* Device pointer + geometry of an internal NHWC activation buffer after se3tn_infer.
- * names: "inA" "inB" [n,176,176,4], "stem" [n,88,88,128]; the conv activations carry a one-pixel
+ * names: "inA" "inB" [n,182,182,4] (3-pixel zero border), "stem" [n,88,88,128]; the conv activations carry a one-pixel
  * zero border: "pool" "t64" "q64" [n,46,46,128] (channels 0-63 branch A, 64-127 branch B),
  * "ab" "ab_t" [n,24,24,256], "head" "head_t" [n,13,13,1024] (0-511 trans, 512-1023 rot).
  * dims = {H, W, C} as stored (borders included). */

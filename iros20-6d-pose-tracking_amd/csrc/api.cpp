@@ -37,7 +37,7 @@ struct se3tn_ctx {
   const float* blob = nullptr;
   BlobLayout L;
   // activations (NHWC float32)
-  float *inA = nullptr, *inB = nullptr;         // [mb,176,176,4]
+  float *inA = nullptr, *inB = nullptr;         // [mb,182,182,4] (3-pixel zero border)
   float* stem = nullptr;                        // [mb,88,88,128]
   // zero-bordered conv activations (se3tn_internal.h: ConvArgs)
   float *pool = nullptr, *t64 = nullptr, *q64 = nullptr;  // [mb,46,46,128]
@@ -61,7 +61,7 @@ struct se3tn_ctx {
 
 extern "C" {
 
-const char* se3tn_version(void) { return "se3tracknet-gfx950 0.1.0 (blob v2)"; }
+const char* se3tn_version(void) { return "se3tracknet-gfx950 0.2.0 (blob v3)"; }
 const char* se3tn_last_error(void) { return g_err.c_str(); }
 
 int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
@@ -85,7 +85,8 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
     const size_t mb = (size_t)max_batch;
     auto padded = [&](int s, int ch) { return (mb * (s + 2) * (s + 2) + PAD_SLACK_PX) * ch; };
     struct { float** p; size_t words; bool zero; } bufs[] = {
-        {&c->inA, mb * RES * RES * 4, false},  {&c->inB, mb * RES * RES * 4, false},
+        {&c->inA, (mb * IN_P + IN_SLACK_ROWS) * IN_P * 4, true},
+        {&c->inB, (mb * IN_P + IN_SLACK_ROWS) * IN_P * 4, true},
         {&c->stem, mb * S1 * S1 * 128, false}, {&c->pool, padded(S2, 128), true},
         {&c->t64, padded(S2, 128), true},      {&c->q64, padded(S2, 128), true},
         {&c->ab, padded(S3, 256), true},       {&c->ab_t, padded(S3, 256), true},
@@ -203,7 +204,9 @@ int se3tn_preprocess(se3tn_ctx* c, const se3tn_crop* crops, int n, float* out, v
   for (int i0 = 0; i0 < n; i0 += CropArgs::MAX) {
     a.n = (n - i0 < CropArgs::MAX) ? n - i0 : CropArgs::MAX;
     std::memcpy(a.c, crops + i0, sizeof(se3tn_crop) * a.n);
-    a.out = out + (size_t)i0 * RES * RES * 4;
+    // the context's own input buffers are zero-bordered [n,182,182,4]; anything else is plain NHWC
+    a.padded = (out == c->inA || out == c->inB) ? 1 : 0;
+    a.out = out + (size_t)i0 * (a.padded ? IN_P * IN_P : RES * RES) * 4;
     HIPCHK(launch_preprocess(a, (hipStream_t)stream));
   }
   return SE3TN_OK;
@@ -236,10 +239,10 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
     HIPCHK(hipEventRecord(c->ev[0], st));
   }
 
-  if (layout == SE3TN_NCHW) {
-    HIPCHK(launch_nchw_to_nhwc4(A, c->inA, n, st));
-    HIPCHK(launch_nchw_to_nhwc4(B, c->inB, n, st));
-    HIPCHK((hipError_t)prof_mark(c, st, "nchw_to_nhwc4 x2", false));
+  if (A != c->inA || B != c->inB) {  // external tensors: copy into the zero-bordered input buffers
+    if (A != c->inA) HIPCHK(launch_to_padded_input(A, c->inA, n, layout == SE3TN_NCHW, st));
+    if (B != c->inB) HIPCHK(launch_to_padded_input(B, c->inB, n, layout == SE3TN_NCHW, st));
+    HIPCHK((hipError_t)prof_mark(c, st, "to_padded_input", false));
     A = c->inA;
     B = c->inB;
   }
@@ -293,7 +296,7 @@ const float* se3tn_logits(se3tn_ctx* c) { return c ? c->logits : nullptr; }
 int se3tn_debug_buffer(se3tn_ctx* c, const char* name, const float** ptr, int32_t dims[3]) {
   if (!c || !name || !ptr || !dims) return fail(SE3TN_E_ARG, "se3tn_debug_buffer: bad argument");
   struct { const char* n; const float* p; int h, w, ch; } t[] = {
-      {"inA", c->inA, RES, RES, 4},      {"inB", c->inB, RES, RES, 4},     {"stem", c->stem, S1, S1, 128},
+      {"inA", c->inA, IN_P, IN_P, 4},    {"inB", c->inB, IN_P, IN_P, 4},     {"stem", c->stem, S1, S1, 128},
       {"pool", c->pool, S2 + 2, S2 + 2, 128},    {"t64", c->t64, S2 + 2, S2 + 2, 128},
       {"q64", c->q64, S2 + 2, S2 + 2, 128},      {"ab", c->ab, S3 + 2, S3 + 2, 256},
       {"ab_t", c->ab_t, S3 + 2, S3 + 2, 256},    {"head", c->head, S4 + 2, S4 + 2, 1024},

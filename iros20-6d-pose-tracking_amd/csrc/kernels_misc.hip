@@ -1,7 +1,8 @@
 // Small HBM-bound kernels either side of the convolution stack:
 //   preprocess   crop_bbox + OffsetDepth + NormalizeChannels + ToTensor  (Utils.py:320-359,
 //                data_augmentation.py:124-189)  -> NHWC float4 pixels
-//   nchw_to_nhwc4  adapter for the reference operator boundary (predict.py:267-271)
+//   to_padded_input  adapter for the reference operator boundary (NCHW, predict.py:267-271) and for
+//                plain NHWC inputs: copies into the zero-bordered [n,182,182,4] layout the stem reads
 //   tail         AdaptiveAvgPool2d(1) + Linear(512,3) + Tanh for both heads
 //                (se3_tracknet.py:72-73,77-78,100-109) + TrackDataset.processPredict
 //                (datasets.py:159-175): t_B = trans*tn + t_A, R_B = Rodrigues(rot*rn) . R_A
@@ -11,21 +12,26 @@
 namespace se3tn {
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ in,
-                                                             float* __restrict__ out, int total) {
+__global__ __launch_bounds__(256) void to_padded_input_kernel(const float* __restrict__ in,
+                                                               float* __restrict__ out, int total, int nchw) {
   const int idx = blockIdx.x * 256 + threadIdx.x;  // (n, y, x)
   if (idx >= total) return;
   constexpr int HW = RES * RES;
   const int n = idx / HW, p = idx - n * HW;
-  const float* src = in + (size_t)n * 4 * HW + p;
+  const int y = p / RES, x = p - y * RES;
   float4 v;
-  v.x = src[0]; v.y = src[HW]; v.z = src[2 * HW]; v.w = src[3 * HW];
-  *reinterpret_cast<float4*>(out + (size_t)idx * 4) = v;
+  if (nchw) {
+    const float* src = in + (size_t)n * 4 * HW + p;
+    v.x = src[0]; v.y = src[HW]; v.z = src[2 * HW]; v.w = src[3 * HW];
+  } else {
+    v = *reinterpret_cast<const float4*>(in + (size_t)idx * 4);
+  }
+  *reinterpret_cast<float4*>(out + (((size_t)n * IN_P + y + IN_PAD) * IN_P + x + IN_PAD) * 4) = v;
 }
 
-hipError_t launch_nchw_to_nhwc4(const float* in, float* out, int n, hipStream_t st) {
+hipError_t launch_to_padded_input(const float* in, float* out, int n, int nchw, hipStream_t st) {
   const int total = n * RES * RES;
-  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, total);
+  hipLaunchKernelGGL(to_padded_input_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, total, nchw);
   return hipGetLastError();
 }
 
@@ -65,7 +71,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const CropArgs a) {
   o.y = (float)(((double)g - mean[1]) / sd[1]);
   o.z = (float)(((double)b - mean[2]) / sd[2]);
   o.w = (float)(((double)d - mean[3]) / sd[3]);
-  *reinterpret_cast<float4*>(a.out + ((size_t)i * RES * RES + p) * 4) = o;
+  float* dst = a.padded ? a.out + (((size_t)i * IN_P + y + IN_PAD) * IN_P + x + IN_PAD) * 4
+                        : a.out + ((size_t)i * RES * RES + p) * 4;
+  *reinterpret_cast<float4*>(dst) = o;
 }
 
 hipError_t launch_preprocess(const CropArgs& a, hipStream_t st) {

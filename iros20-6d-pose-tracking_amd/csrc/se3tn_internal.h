@@ -20,7 +20,8 @@ constexpr int S4 = 11;          // after {trans,rot}_conv1 (s2)
 // single RCCL broadcast.  3x3 convolutions are stored as the MFMA "A" operand panels
 //   [chunk = Cin/32][tap = r*3+s][Cout][32]        (BN folded, see weights.cpp)
 // i.e. for every K-step (chunk,tap) a [Cout][32] row-major tile whose rows are the K-contiguous
-// runs a lane reads with one ds_read_b128.  Stems: [r = 7][Cout = 64][32] with k = s*4+c (s<7).
+// runs a lane reads with one ds_read_b128.  Stems: [Cout = 64][204], k = pair*8 + half*4 + c
+// (tap pairing: weights.cpp pack_stem / stem7x7_mfma.hip).
 // ---------------------------------------------------------------------------------------------
 struct Conv3 {
   int cin, cout, groups;  // weights of `groups` independent convs stored back to back
@@ -43,7 +44,7 @@ enum ConvId {
 
 struct BlobLayout {
   // offsets in float32 words
-  size_t stem_w;   // [2 branches][7][64][32]
+  size_t stem_w;   // [2 branches][64][204]
   size_t stem_b;   // [2][64]
   size_t conv_w[NUM_CONV3];
   size_t conv_b[NUM_CONV3];
@@ -54,7 +55,7 @@ struct BlobLayout {
 
 constexpr int HEADER_WORDS = 64;
 constexpr uint32_t BLOB_MAGIC = 0x53453354u;  // 'SE3T'
-constexpr uint32_t BLOB_VERSION = 2;
+constexpr uint32_t BLOB_VERSION = 3;
 
 inline const Conv3* conv_specs() {
   static const Conv3 s[NUM_CONV3] = {
@@ -66,7 +67,7 @@ inline const Conv3* conv_specs() {
 inline BlobLayout blob_layout() {
   BlobLayout L{};
   size_t o = HEADER_WORDS;
-  L.stem_w = o; o += (size_t)2 * 7 * 64 * 32;
+  L.stem_w = o; o += (size_t)2 * 64 * 204;
   L.stem_b = o; o += 2 * 64;
   const Conv3* s = conv_specs();
   for (int i = 0; i < NUM_CONV3; ++i) {
@@ -87,6 +88,11 @@ inline BlobLayout blob_layout() {
 // stored as [n][H+2][W+2][ld] (+ PAD_SLACK_PX pixels of slack after the last image, the slab DMA
 // rounds its run up to 8 pixels).
 constexpr int PAD_SLACK_PX = 8;
+// The network input (one 16-byte RGBD pixel) is stored with a 3-pixel zero border: [n,182,182,4]
+// (+ IN_SLACK_ROWS rows of slack: the stem's slab DMA always fetches 13 rows).
+constexpr int IN_PAD = 3;
+constexpr int IN_P = RES + 2 * IN_PAD;  // 182
+constexpr int IN_SLACK_ROWS = 6;
 struct ConvArgs {
   const float* in;    // padded NHWC, `in_ld` floats per pixel; channel offset already applied
   const float* w;     // packed panels of group 0
@@ -102,16 +108,18 @@ struct ConvArgs {
   long long w_gs;
 };
 
-struct CropArgs {  // one launch handles up to CROPS_PER_LAUNCH crops
+struct CropArgs {  // one launch handles up to MAX crops
   static constexpr int MAX = 24;
   se3tn_crop c[MAX];
   double mean[8], stdv[8];
-  float* out;  // [n,176,176,4]
+  float* out;   // plain [n,176,176,4], or (padded != 0) the interior of [n,182,182,4]
   int n;
+  int padded;
 };
 
 // launchers (defined in the .hip files)
-hipError_t launch_nchw_to_nhwc4(const float* in, float* out, int n, hipStream_t st);
+// NCHW [n,4,176,176] (nchw != 0) or plain NHWC [n,176,176,4] -> interior of the padded [n,182,182,4]
+hipError_t launch_to_padded_input(const float* in, float* out, int n, int nchw, hipStream_t st);
 hipError_t launch_preprocess(const CropArgs& a, hipStream_t st);
 hipError_t launch_stem(const float* inA, const float* inB, const float* w, const float* bias,
                        float* out, int n, hipStream_t st);

@@ -2,136 +2,243 @@
 // se3_tracknet.py:57,61 -> network_modules.py:59-66), then MaxPool2d(3, s=2, p=1)
 // (se3_tracknet.py:58,62) as a separate streaming kernel.
 //
-// Same exact-f32 MFMA implicit GEMM as conv3x3_mfma.hip with a different gather: the NHWC input
-// has 4 channels = one 16-byte pixel, a K-step is one filter ROW r (7 taps x 4 channels = 28
-// k's, k = s*4+c); 7 K-steps.  Thread t stages tap s = t&7 (s = 7 is an idle slot) of rows
-// (t>>3)+32j: consecutive lanes read consecutive pixels (contiguous 112-byte runs).
+// stem7x7_slab_kernel: exact-f32 MFMA implicit GEMM (rows = output pixels, K = 49 taps x 4
+// channels, N = 64), persistent: 256 workgroups (128 per branch), 8 waves each, loop over tiles of
+// 256 consecutive output pixels of one image.
+//  * the network input is stored with a 3-pixel zero border ([n,182,182,4], one pixel = 16 bytes):
+//    tap (r,s) of output (ho,wo) is padded input pixel (2ho+r, 2wo+s) -- no bounds logic;
+//  * per tile the 13 padded input rows it touches are ONE contiguous 37 KB run: DMA'd
+//    (global_load_lds, purely linear, 4 pieces per M0 setup) into a double-buffered LDS slab while
+//    the previous tile computes; one barrier per TILE;
+//  * the branch's whole folded weight matrix [64][204] (k = pair*8 + half*4 + c, row padded to 816
+//    bytes: conflict-free ds_read_b128) is DMA'd into LDS once per workgroup;
+//  * a pixel is one float4 = one tap's 4 channels.  v_mfma_f32_32x32x2_f32 takes k from lanes 0-31
+//    and k+1 from lanes 32-63, so the two half-waves read two DIFFERENT taps and 4 MFMAs consume
+//    the pair.  Taps are paired so that the half-wave term folds into three lane-constant base
+//    addresses (in-row pairs (r,2j)|(r,2j+1); column-6 pairs (r,6)|(r+1,6); (6,6)|zero weights):
+//    every fragment read of the inner loop is base + compile-time immediate, no VALU at all.
 // Output: [n,88,88,128] NHWC, branch A in channels 0-63, branch B in 64-127.
 #include "se3tn_internal.h"
+
+#ifndef SE3TN_STEM_ABLATE
+#define SE3TN_STEM_ABLATE 0  // timing ablations only: 1 = no output stores, 2 = no slab DMA
+#endif
 
 namespace se3tn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int LDK = 36;
 constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
 constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
 __device__ __forceinline__ float selu_s(float v) {
-  return v > 0.f ? SELU_SCALE * v : (SELU_SCALE * SELU_ALPHA) * expm1f(v);
+  // exp via v_exp_f32: absolute error ~1e-7 on a value of magnitude <= 1.76 (f32-roundoff class)
+  return v > 0.f ? SELU_SCALE * v : (SELU_SCALE * SELU_ALPHA) * (__expf(v) - 1.f);
 }
 
+constexpr int IP = RES + 6;                    // 182: padded input rows / columns
+constexpr int TILE = 256;                      // output pixels per tile
+constexpr int TILES_PER_IMAGE = (S1 * S1 + TILE - 1) / TILE;  // 31 (the last one holds 64 pixels)
+constexpr int SLAB_ROWS = 13;                  // 2 * (4 output rows - 1) + 7
+constexpr int SLAB_PIECES = (SLAB_ROWS * IP * 16 + 1023) / 1024;  // 37 x 1 KB
+constexpr int SLAB_BYTES = SLAB_PIECES * 1024;
+constexpr int WROW = 204;                      // floats per cout row in LDS / in the blob
+constexpr int WBYTES = 64 * WROW * 4;          // 52,224 = 51 x 1 KB
+
 struct StemArgs {
-  const float* in[2];  // [n,176,176,4] per branch
-  const float* w;      // [2][7][64][32]
+  const float* in[2];  // [n,182,182,4] per branch (zero border of 3)
+  const float* w;      // [2][64][204]
   const float* bias;   // [2][64]
   float* out;          // [n,88,88,128]
-  int M;               // n*88*88
+  int n;
 };
 
-__global__ __launch_bounds__(256, 2) void stem7x7_mfma_kernel(const StemArgs a) {
-  constexpr int BM = 128, BN = 64, PR = 4, WR = 2, CT = 2;
-  constexpr int BUF = (BM + BN) * LDK;
-  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+// lane l: LDS[lds + IMM + 16 l] <- global[base + 16 l + IMM]
+template <int IMM>
+__device__ __forceinline__ void dma1k(const float* base, unsigned voff, unsigned lds) {
+  const unsigned long long b_ = (unsigned long long)base;
+  const unsigned blo_ = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)b_);
+  const unsigned bhi_ = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b_ >> 32));
+  const unsigned long long sb_ = ((unsigned long long)bhi_ << 32) | (unsigned long long)blo_;
+  const unsigned lds_ = __builtin_amdgcn_readfirstlane(lds);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 offset:%4\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(lds_), "s"(sb_), "i"(IMM)
+      : "memory");
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+__global__ __launch_bounds__(512, 2) void stem7x7_slab_kernel(const StemArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [weights][slab 0][slab 1]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
-  const int br = blockIdx.y;
-  const int m0 = blockIdx.x * BM;
+  const int nblk = gridDim.x >> 1;
+  const int br = blockIdx.x / nblk, bid = blockIdx.x - br * nblk;
   const float* __restrict__ in = a.in[br];
-  const float* __restrict__ wgt = a.w + (size_t)br * 7 * 64 * 32;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const unsigned lvoff = lane * 16;
+  const int ntiles = a.n * TILES_PER_IMAGE;
 
-  const int s = tid & 7, r0 = tid >> 3;
-  int rowoff[PR], hi0[PR];
-  bool wok[PR];
+  // slab of tile t: padded input rows [2 h0, 2 h0 + 13) of image t / 31, h0 = first output row
+  auto issue_slab = [&](int t, int buf) {
+#if (SE3TN_STEM_ABLATE & 2)
+    return;  // timing ablation: no slab DMA
+#endif
+    const int img = t / TILES_PER_IMAGE, h0 = ((t - img * TILES_PER_IMAGE) * TILE) / S1;
+    const float* src = in + ((size_t)img * IP * IP + (size_t)(2 * h0) * IP) * 4;
+    const unsigned dst = lds0 + WBYTES + buf * SLAB_BYTES;
+    // pieces 4 wid .. 4 wid + 3 with one M0 setup, then pieces 32 + wid for wid < 5
+    const float* s4 = src + wid * 1024;
+    dma1k<0>(s4, lvoff, dst + wid * 4096);
+    dma1k<1024>(s4, lvoff, dst + wid * 4096);
+    dma1k<2048>(s4, lvoff, dst + wid * 4096);
+    dma1k<3072>(s4, lvoff, dst + wid * 4096);
+    if (wid < SLAB_PIECES - 32) dma1k<0>(src + (32 + wid) * 256, lvoff, dst + (32 + wid) * 1024);
+  };
+
+  // weights of this branch: 51 pieces
+  {
+    const float* wsrc = a.w + (size_t)br * 64 * WROW;
 #pragma unroll
-  for (int j = 0; j < PR; ++j) {
-    const int m = m0 + r0 + 32 * j;
-    rowoff[j] = 0; hi0[j] = -1000; wok[j] = false;
-    if (m < a.M) {
-      const int n = m / (S1 * S1), rem = m - n * (S1 * S1);
-      const int ho = rem / S1, wo = rem - ho * S1;
-      const int h0 = 2 * ho - 3, w0 = 2 * wo - 3 + s;
-      hi0[j] = h0;
-      wok[j] = (s < 7) && ((unsigned)w0 < (unsigned)RES);
-      rowoff[j] = ((n * RES + h0) * RES + w0) * 4;
+    for (int j = 0; j < 7; ++j) {
+      const int pc = wid + 8 * j;
+      if (pc < WBYTES / 1024) dma1k<0>(wsrc + pc * 256, lvoff, lds0 + pc * 1024);
     }
   }
-
-  float4 ra[PR], rb[WR];
-  auto load_tile = [&](int r) {
-#pragma unroll
-    for (int j = 0; j < PR; ++j) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (wok[j] && (unsigned)(hi0[j] + r) < (unsigned)RES)
-        v = *reinterpret_cast<const float4*>(in + rowoff[j] + r * (RES * 4));
-      ra[j] = v;
-    }
-    const float* wt = wgt + (size_t)r * (64 * 32) + tid * 4;
-#pragma unroll
-    for (int j = 0; j < WR; ++j) rb[j] = *reinterpret_cast<const float4*>(wt + j * 1024);
-  };
-  auto store_tile = [&](int buf) {
-    float* dst = smem + buf * BUF + r0 * LDK + s * 4;
-#pragma unroll
-    for (int j = 0; j < PR; ++j) *reinterpret_cast<float4*>(dst + (32 * j) * LDK) = ra[j];
-#pragma unroll
-    for (int j = 0; j < WR; ++j) *reinterpret_cast<float4*>(dst + (BM + 32 * j) * LDK) = rb[j];
-  };
-
-  f32x16 acc[CT];
-#pragma unroll
-  for (int j = 0; j < CT; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-
-  load_tile(0);
-  store_tile(0);
+  if (bid < ntiles) issue_slab(bid, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int r = 0; r < 7; ++r) {
-    const int buf = r & 1;
-    if (r + 1 < 7) load_tile(r + 1);
-    const float* pP = smem + buf * BUF + (wid * 32 + l31) * LDK + hh * 2;
-    const float* pW = smem + buf * BUF + (BM + l31) * LDK + hh * 2;
+
+  const unsigned char* wl = smem + (l31 * WROW + hh * 4) * 4;  // + ct * 32 rows + pair * 32 bytes
+  // lane-constant bias values (8 x float4), loaded once: an epilogue that loads them per tile waits
+  // an L2 round trip per load
+  float4 bias_r[2][4];
 #pragma unroll
-    for (int kg = 0; kg < 7; ++kg) {  // 4 k's per group: lanes 0-31 take k, k+1; lanes 32-63 k+2, k+3
-      const float2 pv = *reinterpret_cast<const float2*>(pP + kg * 4);
-      float2 wv[CT];
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < CT; ++j) wv[j] = *reinterpret_cast<const float2*>(pW + j * 32 * LDK + kg * 4);
+    for (int q = 0; q < 4; ++q)
+      bias_r[j][q] = *reinterpret_cast<const float4*>(a.bias + br * 64 + j * 32 + q * 8 + hh * 4);
+
+  auto epilogue = [&](const f32x16 (&acc)[2], float* __restrict__ out) {
 #pragma unroll
-      for (int j = 0; j < CT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].x, pv.x, acc[j], 0, 0, 0);
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < CT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].y, pv.y, acc[j], 0, 0, 0);
+      for (int q = 0; q < 4; ++q) {
+        const int c = j * 32 + q * 8 + hh * 4;
+        const float4 b = bias_r[j][q];
+        float4 v;
+        v.x = selu_s(acc[j][4 * q + 0] + b.x);
+        v.y = selu_s(acc[j][4 * q + 1] + b.y);
+        v.z = selu_s(acc[j][4 * q + 2] + b.z);
+        v.w = selu_s(acc[j][4 * q + 3] + b.w);
+#if (SE3TN_STEM_ABLATE & 1)
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));  // timing ablation: no stores
+#else
+        *reinterpret_cast<float4*>(out + c) = v;
+#endif
+      }
+  };
+
+  // The 8 waves of the workgroup run in lock-step (one barrier per tile), and waves w and w+4
+  // share a SIMD.  If both did [MFMA][epilogue] the matrix pipe would idle during every epilogue, so
+  // waves 4-7 run one tile behind on the epilogue: [epilogue of the previous tile][MFMA], which puts
+  // each SIMD's two waves in complementary phases.
+  const bool deferred = wid >= 4;
+  f32x16 held[2];
+  float* held_out = nullptr;
+
+  int it = 0;
+  for (int t = bid; t < ntiles; t += nblk, ++it) {
+    const int buf = it & 1;
+    if (t + nblk < ntiles) issue_slab(t + nblk, buf ^ 1);
+    if (deferred && held_out) epilogue(held, held_out);
+
+    const int img = t / TILES_PER_IMAGE, p0 = (t - img * TILES_PER_IMAGE) * TILE;
+    const int h0 = p0 / S1;
+    const int p = p0 + wid * 32 + l31;         // output pixel of this lane within the image
+    const bool ok = p < S1 * S1;
+    const int pc = ok ? p : S1 * S1 - 1;
+    const int ho = pc / S1, wo = pc - ho * S1;
+    const unsigned char* sl = smem + WBYTES + buf * SLAB_BYTES + ((2 * (ho - h0)) * IP + 2 * wo) * 16;
+    const unsigned char* slA = sl + hh * 16;        // in-row pairs: half-wave 1 reads tap s+1
+    const unsigned char* slB = sl + hh * IP * 16;   // column-6 pairs: half-wave 1 reads row r+1
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // fragments of pair k+1 are fetched before the 8 MFMAs of pair k are issued (hipcc otherwise
+    // re-uses one register set and exposes an LDS round trip per pair); all addresses are
+    // base + compile-time immediate
+#define STEM_LOAD(F, K)                                                                              \
+    {                                                                                               \
+      constexpr int k_ = (K);                                                                       \
+      const unsigned char* px_ = k_ < 21 ? slA + ((k_ / 3) * IP + 2 * (k_ % 3)) * 16                 \
+                                 : k_ < 24 ? slB + (2 * (k_ - 21) * IP + 6) * 16                     \
+                                           : sl + (6 * IP + 6) * 16;                                \
+      F##p = *reinterpret_cast<const float4*>(px_);                                                 \
+      F##w0 = *reinterpret_cast<const float4*>(wl + k_ * 32);                                       \
+      F##w1 = *reinterpret_cast<const float4*>(wl + 32 * WROW * 4 + k_ * 32);                       \
     }
-    if (r + 1 < 7) store_tile(buf ^ 1);
+#define STEM_MMA(F)                                                                                 \
+    {                                                                                               \
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##w0.x, F##p.x, acc[0], 0, 0, 0);              \
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##w1.x, F##p.x, acc[1], 0, 0, 0);              \
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##w0.y, F##p.y, acc[0], 0, 0, 0);              \
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##w1.y, F##p.y, acc[1], 0, 0, 0);              \
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##w0.z, F##p.z, acc[0], 0, 0, 0);              \
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##w1.z, F##p.z, acc[1], 0, 0, 0);              \
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##w0.w, F##p.w, acc[0], 0, 0, 0);              \
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##w1.w, F##p.w, acc[1], 0, 0, 0);              \
+    }
+#define STEM_FENCE __builtin_amdgcn_sched_barrier(0);  /* keeps the next pair's reads ahead of the MFMAs */
+#define STEM_STEP2(K)   /* pairs K (set A) and K+1 (set B); set A of pair K is already loaded */     \
+    STEM_LOAD(fB, (K) + 1) STEM_FENCE STEM_MMA(fA) STEM_LOAD(fA, (K) + 2) STEM_FENCE STEM_MMA(fB)
+    float4 fAp, fAw0, fAw1, fBp, fBw0, fBw1;
+    STEM_LOAD(fA, 0)
+    STEM_STEP2(0) STEM_STEP2(2) STEM_STEP2(4) STEM_STEP2(6) STEM_STEP2(8) STEM_STEP2(10)
+    STEM_STEP2(12) STEM_STEP2(14) STEM_STEP2(16) STEM_STEP2(18) STEM_STEP2(20)
+    STEM_LOAD(fB, 23) STEM_FENCE STEM_MMA(fA) STEM_LOAD(fA, 24) STEM_FENCE STEM_MMA(fB)
+    STEM_MMA(fA)
+#undef STEM_FENCE
+#undef STEM_STEP2
+#undef STEM_MMA
+#undef STEM_LOAD
+
+    float* out = ok ? a.out + ((size_t)img * S1 * S1 + p) * 128 + br * 64 : nullptr;
+    if (deferred) {
+      held[0] = acc[0]; held[1] = acc[1];
+      held_out = out;
+    } else if (out) {
+      epilogue(acc, out);
+    }
+    // next tile's slab has had this tile's 200 MFMAs per wave to land
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-
-  const int m = m0 + wid * 32 + l31;
-  if (m >= a.M) return;
-  const float* __restrict__ bias = a.bias + br * 64;
-  float* __restrict__ out = a.out + (size_t)m * 128 + br * 64;
-#pragma unroll
-  for (int j = 0; j < CT; ++j)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = j * 32 + q * 8 + hh * 4;
-      const float4 b = *reinterpret_cast<const float4*>(bias + c);
-      float4 v;
-      v.x = selu_s(acc[j][4 * q + 0] + b.x);
-      v.y = selu_s(acc[j][4 * q + 1] + b.y);
-      v.z = selu_s(acc[j][4 * q + 2] + b.z);
-      v.w = selu_s(acc[j][4 * q + 3] + b.w);
-      *reinterpret_cast<float4*>(out + c) = v;
-    }
+  if (deferred && held_out) epilogue(held, held_out);
 }
 
 hipError_t launch_stem(const float* inA, const float* inB, const float* w, const float* bias,
                        float* out, int n, hipStream_t st) {
+  constexpr size_t lds = WBYTES + 2 * SLAB_BYTES;  // 128,000 B
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7x7_slab_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
   StemArgs a;
-  a.in[0] = inA; a.in[1] = inB; a.w = w; a.bias = bias; a.out = out;
-  a.M = n * S1 * S1;
-  const dim3 grid((a.M + 127) / 128, 2);
-  hipLaunchKernelGGL(stem7x7_mfma_kernel, grid, dim3(256), 0, st, a);
+  a.in[0] = inA; a.in[1] = inB; a.w = w; a.bias = bias; a.out = out; a.n = n;
+  const int ntiles = n * TILES_PER_IMAGE;
+  const int per_branch = ntiles < 128 ? ntiles : 128;  // one workgroup per CU, half the chip per branch
+  hipLaunchKernelGGL(stem7x7_slab_kernel, dim3(2 * per_branch), dim3(512), lds, st, a);
   return hipGetLastError();
 }
 

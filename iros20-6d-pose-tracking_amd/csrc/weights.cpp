@@ -84,14 +84,31 @@ void pack3(const Folded& f, float* dst, int cout_total, int o_off) {
               f.w[(((size_t)o * f.cin) + ch * 32 + ci) * 9 + tap];
 }
 
-// OIHW 7x7, Cin=4 -> [r][64][32], k = s*4 + c, k >= 28 zero
+// OIHW 7x7, Cin=4 -> [64][204]: k = pair*8 + half*4 + c, the (tap of half 0 | tap of half 1) pairs in
+// the order stem7x7_mfma.hip walks them: 21 in-row pairs (r,2j)|(r,2j+1), 3 column-6 pairs
+// (2j,6)|(2j+1,6), then (6,6)|zero.  k 200..203 pad the row to 816 bytes.
 void pack_stem(const Folded& f, float* dst) {
-  std::memset(dst, 0, sizeof(float) * 7 * 64 * 32);
+  std::memset(dst, 0, sizeof(float) * 64 * 204);
+  int taps[25][2][2];  // [pair][half] -> (r, s); r = -1: zero weights
+  int np = 0;
   for (int r = 0; r < 7; ++r)
-    for (int o = 0; o < 64; ++o)
-      for (int s = 0; s < 7; ++s)
+    for (int sp = 0; sp < 3; ++sp, ++np) {
+      taps[np][0][0] = r; taps[np][0][1] = 2 * sp;
+      taps[np][1][0] = r; taps[np][1][1] = 2 * sp + 1;
+    }
+  for (int j = 0; j < 3; ++j, ++np) {
+    taps[np][0][0] = 2 * j;     taps[np][0][1] = 6;
+    taps[np][1][0] = 2 * j + 1; taps[np][1][1] = 6;
+  }
+  taps[np][0][0] = 6; taps[np][0][1] = 6; taps[np][1][0] = -1; taps[np][1][1] = 0;
+  for (int o = 0; o < 64; ++o)
+    for (int pr = 0; pr < 25; ++pr)
+      for (int h = 0; h < 2; ++h) {
+        const int r = taps[pr][h][0], sx = taps[pr][h][1];
+        if (r < 0) continue;
         for (int c = 0; c < 4; ++c)
-          dst[((size_t)r * 64 + o) * 32 + s * 4 + c] = f.w[(((size_t)o * 4 + c) * 7 + r) * 7 + s];
+          dst[(size_t)o * 204 + pr * 8 + h * 4 + c] = f.w[(((size_t)o * 4 + c) * 7 + r) * 7 + sx];
+      }
 }
 
 }  // namespace
@@ -108,7 +125,7 @@ std::string pack_blob(const TensorMap& t, std::vector<float>& blob) {
   const char* stems[2] = {"convA1", "convB1"};
   for (int br = 0; br < 2; ++br) {
     Folded f = fold(t, std::string(stems[br]) + ".0", std::string(stems[br]) + ".1");
-    pack_stem(f, blob.data() + L.stem_w + (size_t)br * 7 * 64 * 32);
+    pack_stem(f, blob.data() + L.stem_w + (size_t)br * 64 * 204);
     std::memcpy(blob.data() + L.stem_b + br * 64, f.b.data(), 64 * sizeof(float));
   }
   struct Src { ConvId id; int group; int o_off; int cout_total; const char* conv; const char* bn; };

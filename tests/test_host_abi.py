@@ -74,9 +74,14 @@ def _numpy_pack(sd):
 
     parts = [np.zeros(64, np.float32)]
     stems = [fold(n + ".0", n + ".1") for n in ("convA1", "convB1")]
-    for w, _ in stems:
-        t = np.zeros((7, 64, 32), np.float32)
-        t[:, :, :28] = w.transpose(2, 0, 3, 1).reshape(7, 64, 28)  # [r][o][s*4+c]
+    pairs = [((r, 2 * sp), (r, 2 * sp + 1)) for r in range(7) for sp in range(3)]
+    pairs += [((2 * j, 6), (2 * j + 1, 6)) for j in range(3)] + [((6, 6), None)]
+    for w, _ in stems:  # [o][pair*8 + half*4 + c], row padded to 204
+        t = np.zeros((64, 204), np.float32)
+        for pi, pr in enumerate(pairs):
+            for h, tap in enumerate(pr):
+                if tap is not None:
+                    t[:, pi * 8 + h * 4: pi * 8 + h * 4 + 4] = w[:, :, tap[0], tap[1]]
         parts.append(t.reshape(-1))
     parts += [b for _, b in stems]
     groups = [[("convA2.conv1", "convA2.bn1"), ("convB2.conv1", "convB2.bn1")],
