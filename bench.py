@@ -150,13 +150,17 @@ def main():
                        "pairs_per_gpu": nb, "global_batch": world * nb, "stage": args.stage,
                        "parallelism": "frame-sharded x%d, RCCL weight broadcast + pose all-gather" % world},
             "tflops_total": round(value * FLOP_PER_PAIR / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (10 launches/step, exact-f32 v_mfma_f32_32x32x2_f32)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_slab_kernel + conv3x3_gather_s2_kernel (10 launches/step, exact-f32 v_mfma_f32_32x32x2_f32)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                          "conv_ms_per_step": round(conv_ms_avg, 4), "all_kernels_ms_per_step": round(float(np.mean(tot_ms)), 4),
                          "flop_per_step": CONV3_FLOP_PER_PAIR * nb},
             "layers_ms": {n: round(ms, 4) for n, ms in layers},
         }
+        tr, src = pmc_traffic(nb)
+        if tr is not None:
+            out["roofline"]["traffic"] = int(tr)
+            out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per step)" % src
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(O, sd, nb)
         if args.layers:
@@ -165,6 +169,25 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(nb):
+    """HBM bytes per step of the conv3x3 family from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc.json: FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, KB, separate passes of
+    this same command at batch 64).  Not collected live (PMC needs rocprofv3 around the process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files or nb != 64:
+        return None, None
+    d = json.load(open(files[-1]))
+    # launches per step of each instantiation: 64-ch kernels run twice (grouped A|B pair + B3 alone)
+    total = 0.0
+    for k, v in d["fetch"].items():
+        if not k.startswith("conv3x3"):
+            continue
+        calls = 2 if "<64," in k else 1
+        total += calls * (2.0 * v["FETCH_SIZE"] + d["write"][k]["WRITE_SIZE"]) * 1024.0
+    return total, os.path.basename(files[-1])
 
 
 def cpu_baseline(O, sd, nb):
