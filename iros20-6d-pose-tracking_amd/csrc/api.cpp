@@ -44,6 +44,8 @@ struct se3tn_ctx {
   float *ab = nullptr, *ab_t = nullptr;         // [mb,24,24,256]
   float *head = nullptr, *head_t = nullptr;     // [mb,13,13,1024]
   float* logits = nullptr;                      // [mb,6]
+  float* part = nullptr;                        // split-K partial sums (small-batch latency path)
+  size_t part_bytes = 0;
   double mean[8], stdv[8];
   bool have_norm = false;
   double tn = 0.03, rn = 5.0 * 3.14159265358979323846 / 180.0;
@@ -99,6 +101,10 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
       if (b.zero) e = hipMemset(*b.p, 0, b.words * sizeof(float));
       if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMemset(workspace)"); }
     }
+    // split-K workspace: 16 slices of the widest layer (1024 couts x 121 px) up to batch 16
+    c->part_bytes = (size_t)16 * 1024 * 121 * 16 * sizeof(float);
+    e = hipMalloc((void**)&c->part, c->part_bytes);
+    if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(split-K workspace)"); }
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipDeviceSynchronize"); }
   }
@@ -110,7 +116,7 @@ void se3tn_destroy(se3tn_ctx* c) {
   if (!c) return;
   if (c->device >= 0) {
     float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
-                     c->head_t, c->logits, c->blob_owned};
+                     c->head_t, c->logits, c->part, c->blob_owned};
     for (float* b : bufs)
       if (b) (void)hipFree(b);
     for (int s = 0; s < c->slots; ++s)
@@ -255,7 +261,7 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
                   float* out, int out_ld, int out_gs, int hin, int stride, int epi, const char* name) -> int {
     const Conv3& s = conv_specs()[id];
     ConvArgs a{};
-    a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id]; a.res = res; a.out = out;
+    a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id]; a.res = res; a.out = out; a.part = c->part; a.part_bytes = c->part_bytes;
     a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
     a.H = hin; a.W = hin; a.Ho = (hin - 1) / stride + 1; a.Wo = a.Ho;
     a.M = n * a.Ho * a.Wo;

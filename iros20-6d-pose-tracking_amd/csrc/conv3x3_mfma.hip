@@ -388,6 +388,139 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gather_s2_kernel(const ConvArg
   store_tiles<PT, CT, EPI>(a, g, acc, opix, ok, n0 + wn * CT * 32, hh);
 }
 
+// =================================================================================================
+// small-batch (latency) path: split-K.  At batch 1 the big-tile kernels above would occupy 8-64 of
+// the 256 CUs (M = 121..1936 rows), so the K dimension is cut into `slices` runs of 32-channel chunks
+// handled by different workgroups (128 px x {128|64} cout, 4 waves, per-tap gather on the
+// zero-bordered input, stride 1 or 2).  Each workgroup stores its raw partial accumulators to
+// part[slice][group][M][cout]; conv_reduce_kernel sums the slices in a FIXED order (deterministic,
+// no atomics) and applies the bias / residual / activation epilogue into the padded output.
+// =================================================================================================
+template <int CIN, int STRIDE, int CT>
+__global__ __launch_bounds__(256, 2) void conv3x3_splitk_kernel(const ConvArgs a) {
+  constexpr int BM = 128, BN = 64 * CT, PT = 2;
+  constexpr int NCH = CIN / 32;
+  constexpr int WR = BN / 32;  // weight rows per staging thread
+  constexpr int BUF = (BM + BN) * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  const int panels = a.groups * a.tiles_n;
+  const int sl = blockIdx.x % a.slices, rest = blockIdx.x / a.slices;
+  const int p = rest % panels, mt = rest / panels;
+  const int g = p / a.tiles_n, nt = p % a.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const float* __restrict__ in = a.in + (size_t)g * a.in_gs;
+  const float* __restrict__ wgt = a.w + (size_t)g * a.w_gs + (size_t)n0 * 32;
+  const int Wp = a.W + 2, Hp = a.H + 2, HoWo = a.Ho * a.Wo;
+  const int mlast = a.M - 1;
+  const int cps = NCH / a.slices, ch0 = sl * cps, KT = cps * 9;
+
+  const int r0 = tid >> 3;
+  const int c4 = (tid & 7) ^ ((r0 >> 1) & 7);
+  unsigned pvoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = min(m0 + r0 + 32 * j, mlast);
+    const int n = m / HoWo, rem = m - n * HoWo;
+    const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    pvoff[j] = (unsigned)((((n * Hp + STRIDE * ho) * Wp + STRIDE * wo) * a.in_ld + c4 * 4) * 4);
+  }
+  const unsigned wvoff = (unsigned)((r0 * 32 + c4 * 4) * 4);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+#define ISSUE_TILE(CH, TAP, BUFI)                                                                    \
+  {                                                                                                  \
+    const int r_ = (TAP) / 3, s_ = (TAP) - r_ * 3;                                                   \
+    const float* pb_ = in + (size_t)(r_ * Wp + s_) * a.in_ld + (CH) * 32;                            \
+    const unsigned lb_ = lds0 + (unsigned)(((BUFI) * BUF + wid * 256) * 4);                          \
+    glds16<0>(pb_, pvoff[0], lb_);                                                                   \
+    glds16<0>(pb_, pvoff[1], lb_ + 4096);                                                            \
+    glds16<0>(pb_, pvoff[2], lb_ + 8192);                                                            \
+    glds16<0>(pb_, pvoff[3], lb_ + 12288);                                                           \
+    const float* tb_ = wgt + (size_t)((CH) * 9 + (TAP)) * (a.tiles_n * BN) * 32;                     \
+    _Pragma("unroll") for (int j = 0; j < WR; ++j)                                                   \
+        glds16<0>(tb_ + j * 1024, wvoff, lb_ + BM * 128 + j * 4096);                                 \
+  }
+
+  const int X = (l31 >> 1) & 7;
+  const int lo = (hh ^ (X & 1)) * 4, xk = X >> 1;
+  const int fo0 = ((0 ^ xk) << 3) + lo, fo1 = ((1 ^ xk) << 3) + lo, fo2 = ((2 ^ xk) << 3) + lo,
+            fo3 = ((3 ^ xk) << 3) + lo;
+
+  f32x16 acc[PT][CT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  ISSUE_TILE(ch0, 0, 0)
+  wait_dma_and_barrier();
+
+  int ch = ch0, tap = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (++tap == 9) { tap = 0; ++ch; }
+    if (kt + 1 < KT) ISSUE_TILE(ch, tap, buf ^ 1)
+    const float* pP = smem + buf * BUF + (wm * PT * 32 + l31) * 32;
+    const float* pW = smem + buf * BUF + (BM + wn * CT * 32 + l31) * 32;
+    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo0),
+                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo0))
+    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo1),
+                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo1))
+    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo2),
+                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo2))
+    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo3),
+                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo3))
+    if (kt + 1 < KT) wait_dma_and_barrier();
+  }
+#undef ISSUE_TILE
+
+  // raw partial sums: part[slice][group][m][cout]
+  const int cout = a.tiles_n * BN;
+  float* __restrict__ part = a.part + ((size_t)(sl * a.groups + g) * a.M) * cout;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int m = m0 + (wm * PT + i) * 32 + l31;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = n0 + (wn * CT + j) * 32 + q * 8 + hh * 4;
+        *reinterpret_cast<float4*>(part + (size_t)m * cout + c) =
+            make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvArgs a, int cout, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (group, m, c4)
+  if (idx >= total) return;
+  const int q4 = cout >> 2;
+  const int c = (idx % q4) * 4, t = idx / q4;
+  const int m = t % a.M, g = t / a.M;
+  const size_t slice_stride = (size_t)a.groups * a.M * cout;
+  const float* src = a.part + ((size_t)g * a.M + m) * cout + c;
+  float4 v = *reinterpret_cast<const float4*>(src);
+  for (int s = 1; s < a.slices; ++s) {  // fixed order: deterministic
+    const float4 u = *reinterpret_cast<const float4*>(src + s * slice_stride);
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  const int opix = padded_index(m, a.Ho * a.Wo, a.Wo);
+  const float4 b = *reinterpret_cast<const float4*>(a.bias + (size_t)g * a.bias_gs + c);
+  v = apply_epilogue<EPI>(v, b, (EPI == 1) ? a.res + (size_t)g * a.res_gs + (size_t)opix * a.res_ld + c : nullptr);
+  *reinterpret_cast<float4*>(a.out + (size_t)g * a.out_gs + (size_t)opix * a.out_ld + c) = v;
+}
+
 // ---- launchers ---------------------------------------------------------------------------------
 template <typename K>
 static hipError_t set_lds(K kern, size_t lds, bool& done) {
@@ -424,11 +557,57 @@ static hipError_t launch_gather(const ConvArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <int CIN, int STRIDE, int CT>
+static hipError_t launch_splitk(const ConvArgs& a, int epi, hipStream_t st) {
+  constexpr int BN = 64 * CT;
+  constexpr size_t lds = (size_t)2 * (128 + BN) * 32 * sizeof(float);
+  auto kern = conv3x3_splitk_kernel<CIN, STRIDE, CT>;
+  static bool attr = false;
+  hipError_t e = set_lds(kern, lds, attr);
+  if (e != hipSuccess) return e;
+  const int tiles_m = (a.M + 127) / 128;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * a.tiles_n * a.groups * a.slices), dim3(256), lds, st, a);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int cout = a.tiles_n * BN;
+  const int total = a.groups * a.M * (cout / 4);
+  const dim3 grid((total + 255) / 256);
+  if (epi == 0) hipLaunchKernelGGL(conv_reduce_kernel<0>, grid, dim3(256), 0, st, a, cout, total);
+  else if (epi == 1) hipLaunchKernelGGL(conv_reduce_kernel<1>, grid, dim3(256), 0, st, a, cout, total);
+  else hipLaunchKernelGGL(conv_reduce_kernel<2>, grid, dim3(256), 0, st, a, cout, total);
+  return hipGetLastError();
+}
+
+// Split-K is used when the big-tile grid would leave most of the 256 CUs idle and the partial-sum
+// workspace is large enough; slices = the smallest power of two that yields >= 512 workgroups.
+static int pick_slices(const ConvArgs& a, int cin, int cout, int big_tile_rows, int bn_big) {
+  const int big_blocks = ((a.M + big_tile_rows - 1) / big_tile_rows) * (cout / bn_big) * a.groups;
+  if (big_blocks >= 200 || a.part == nullptr) return 0;
+  const int bn = cout >= 128 ? 128 : 64;
+  const int base = ((a.M + 127) / 128) * (cout / bn) * a.groups;
+  const int nch = cin / 32;
+  int slices = 1;
+  while (slices < nch && base * slices < 512) slices *= 2;
+  const size_t per_slice = (size_t)a.groups * a.M * cout * sizeof(float);
+  while (slices > 1 && per_slice * slices > a.part_bytes) slices /= 2;
+  return per_slice * slices <= a.part_bytes ? slices : 0;
+}
+
 // Slab sizes (pixels, multiple of 8) = worst case of
 //   255 + 2 per row break + (2 Wp + 2) per image break + 2 (Wp + 1) + 1     (tests/test_slab_geometry.py)
 //   W = 44: 454 -> 464     W = 22: 378 -> 384     W = 11: 410 -> 424
 hipError_t launch_conv3x3(const ConvArgs& a0, int cin, int cout, int stride, int epi, hipStream_t st) {
   ConvArgs a = a0;
+  a.slices = pick_slices(a, cin, cout, stride == 1 ? 256 : 128, cout >= 128 ? 128 : 64);
+  if (a.slices > 0) {
+    a.tiles_n = cout >= 128 ? cout / 128 : 1;
+    if (cin == 64 && stride == 1) return launch_splitk<64, 1, 1>(a, epi, st);
+    if (cin == 128 && stride == 2) return launch_splitk<128, 2, 2>(a, epi, st);
+    if (cin == 256 && stride == 1) return launch_splitk<256, 1, 2>(a, epi, st);
+    if (cin == 256 && stride == 2) return launch_splitk<256, 2, 2>(a, epi, st);
+    if (cin == 512 && stride == 1) return launch_splitk<512, 1, 2>(a, epi, st);
+    return hipErrorInvalidValue;
+  }
   if (stride == 1 && cin == 64 && cout == 64 && a.W == 44) {
     a.tiles_n = 1;
     if (epi == 0) return launch_slab<64, 8, 1, 1, 2, 464, 0>(a, st);

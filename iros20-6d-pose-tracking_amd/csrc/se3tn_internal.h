@@ -106,6 +106,10 @@ struct ConvArgs {
   int groups;         // independent convolutions in this launch
   int in_gs, res_gs, out_gs, bias_gs;  // per-group strides (floats)
   long long w_gs;
+  // small-batch split-K path (conv3x3_splitk_kernel): partial-sum workspace, 0 slices = not used
+  float* part;
+  size_t part_bytes;
+  int slices;
 };
 
 struct CropArgs {  // one launch handles up to MAX crops

@@ -111,9 +111,10 @@ def test_forward_big_inputs_second_seed(se3, golden_dir):
 
 
 def test_batch64_rows_equal_batch1_and_ragged_tail(se3, model0):
-    """Size-independent property at BASELINE's batch: every pair of a batch-64 call gives the
-    same answer as that pair alone (tiles straddle pair boundaries; 64*1936 etc. are not tile
-    multiples), and n=5 (ragged last tile everywhere) agrees as well."""
+    """Size-independent property at BASELINE's batch: every pair of a batch-64 call (big-tile slab
+    kernels) gives the same answer as that pair alone (split-K latency kernels; tiles straddle pair
+    boundaries; 64*1936 etc. are not tile multiples), and n=5 (ragged last tile everywhere) and n=20
+    (mixed: some layers split-K, some not) agree as well.  Different summation orders: f32 noise."""
     model, sd = model0
     A, B = Fx.net_inputs(5, 64)
     Ac, Bc = A.cuda(), B.cuda()
@@ -123,10 +124,16 @@ def test_batch64_rows_equal_batch1_and_ragged_tail(se3, model0):
     for i in (0, 17, 63):
         o1 = model(Ac[i:i + 1], Bc[i:i + 1], return_feature=False)
         l1 = model.engine.logits(1)
-        assert float((l1[0] - l64[i]).abs().max()) < 2e-6
-        assert float((o1["trans"][0] - t64[i]).abs().max()) < 2e-6
+        assert float((l1[0] - l64[i]).abs().max()) < 5e-6
+        assert float((o1["trans"][0] - t64[i]).abs().max()) < 5e-6
     o5 = model(Ac[10:15], Bc[10:15], return_feature=False)
-    assert float((o5["rot"] - r64[10:15]).abs().max()) < 2e-6
+    assert float((o5["rot"] - r64[10:15]).abs().max()) < 5e-6
+    o20 = model(Ac[30:50], Bc[30:50], return_feature=False)
+    assert float((o20["trans"] - t64[30:50]).abs().max()) < 5e-6
+    # the split-K path sums its slices in a fixed order: bit-reproducible run to run
+    o1a = model(Ac[7:8], Bc[7:8], return_feature=False)["trans"].clone()
+    o1b = model(Ac[7:8], Bc[7:8], return_feature=False)["trans"].clone()
+    assert (o1a == o1b).all()
     # spot-check 2 of the 64 against the CPU oracle
     ref = O.forward(sd, A[[3, 40]], B[[3, 40]])
     _close("b64 trans", t64[[3, 40]].cpu(), ref["trans"], 0, NET_TOL)
