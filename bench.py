@@ -56,7 +56,9 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    if world > 1:
+    # SE3TN_FORCE_DIST=1: run the RCCL code path (weight broadcast, pose all-gather) even at world 1
+    use_dist = world > 1 or (os.environ.get("SE3TN_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
     dist_mod = __import__("importlib").import_module("iros20-6d-pose-tracking_amd.dist")
@@ -64,7 +66,7 @@ def main():
     nb = args.batch
     eng = se3.Engine(local_rank, nb)
     sd = O.make_state_dict(0) if rank == 0 else None
-    if world > 1:
+    if use_dist:
         dist_mod.load_weights_everywhere(eng, sd)       # C1: RCCL broadcast of the packed blob
     else:
         eng.load_state_dict(sd)
@@ -102,7 +104,7 @@ def main():
             eng.preprocess(cropsA, inA)
             eng.preprocess(cropsB, inB)
         eng.infer(inA, inB, nb, se3.NHWC, trans, rot, poseA, poseB)
-        if world > 1:
+        if use_dist:
             return dist_mod.gather_poses(poseB)      # C2
         return poseB
 
@@ -111,18 +113,18 @@ def main():
     slots = min(args.steps, 64)
     eng.profile_enable(slots)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -167,7 +169,7 @@ def main():
             for n, ms in layers:
                 print("%-32s %8.3f ms" % (n, ms), file=sys.stderr)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
