@@ -1,0 +1,185 @@
+"""GPU: edge cases of the hot path, through the C ABI, against the CPU oracle.
+
+Covers what the domain offers as "ragged / empty / maximum / null" inputs: crop windows that
+leave the frame on every side or miss it entirely, all-invalid depth, up- and down-sampling crops,
+odd frame sizes, negative-z (GL) poses, external NHWC inputs, batch == max_batch, samples > 1,
+and argument errors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fixtures as Fx
+from oracle import se3_oracle as O
+
+
+@pytest.fixture(scope="module")
+def se3():
+    import se3tracknet_amd
+    return se3tracknet_amd
+
+
+def _oracle_crop(rgb, depth, win, z_mm, mean, std, stats):
+    """oracle for one se3tn_crop: crop window (l,t,r,b) -> normalised [4,176,176]."""
+    l, t, r, b = win
+    bb = np.array([[t, l], [b, l], [t, r], [b, r]], np.int32)
+    H, W = depth.shape
+    if r <= 0 or b <= 0 or l >= W or t >= H:  # window misses the frame: the reference's slicing would
+        rgbc = np.zeros((176, 176, 3), np.uint8); dc = np.zeros((176, 176), np.uint16)  # raise; zeros here
+    else:
+        rgbc, dc = O.crop_bbox(rgb, depth, bb, (176, 176))
+    P = np.eye(4); P[2, 3] = z_mm / 1000.0
+    d = O.normalize_depth(dc, P)
+    return O.normalize_channels(rgbc.astype(np.float32), d, mean[4 * stats:4 * stats + 4], std[4 * stats:4 * stats + 4])
+
+
+WINDOWS = [
+    ("inside", (213, 48, 546, 381)),
+    ("left_top_out", (-120, -90, 200, 230)),
+    ("right_bottom_out", (500, 300, 900, 700)),
+    ("all_sides_out", (-50, -60, 700, 560)),
+    ("tiny_upsample", (300, 200, 317, 217)),
+    ("one_pixel", (100, 100, 101, 101)),
+    ("non_square", (10, 20, 400, 150)),
+    ("entirely_outside", (700, 500, 900, 700)),
+    ("huge", (-2000, -2000, 2600, 2500)),
+]
+
+
+@pytest.mark.parametrize("name,win", WINDOWS, ids=[w[0] for w in WINDOWS])
+def test_preprocess_windows_bit_exact(se3, name, win):
+    rng = np.random.default_rng(5)
+    H, W = 480, 640
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    depth = rng.integers(0, 2500, (H, W)).astype(np.uint16)
+    mean, std = Fx.mean_std(3)
+    eng = se3.Engine(0, 1)
+    eng.set_normalization(mean, std)
+    out = torch.empty((1, 176, 176, 4), device="cuda")
+    for z_mm, stats in ((812.5, 1), (-640.25, 0)):  # positive (cv) and negative (gl) poseA z
+        eng.preprocess([dict(rgb=torch.from_numpy(rgb).cuda(), depth=torch.from_numpy(depth.view(np.int16)).cuda(),
+                             window=win, z_offset_mm=z_mm, stats=stats)], out)
+        got = out[0].permute(2, 0, 1).cpu().numpy()
+        want = _oracle_crop(rgb, depth, win, z_mm, mean, std, stats)
+        assert (got == want).all(), (name, float(np.abs(got - want).max()))
+
+
+def test_preprocess_odd_frame_and_all_invalid_depth(se3):
+    rng = np.random.default_rng(9)
+    H, W = 97, 131
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    mean, std = Fx.mean_std(4)
+    eng = se3.Engine(0, 3)
+    eng.set_normalization(mean, std)
+    out = torch.empty((3, 176, 176, 4), device="cuda")
+    depths = [np.zeros((H, W), np.uint16), np.full((H, W), 100, np.uint16), np.full((H, W), 65535, np.uint16)]
+    crops = [dict(rgb=torch.from_numpy(rgb).cuda(), depth=torch.from_numpy(d.view(np.int16)).cuda(),
+                  window=(-5, 3, 120, 90), z_offset_mm=700.0, stats=1) for d in depths]
+    eng.preprocess(crops, out)
+    for i, d in enumerate(depths):
+        want = _oracle_crop(rgb, d, (-5, 3, 120, 90), 700.0, mean, std, 1)
+        got = out[i].permute(2, 0, 1).cpu().numpy()
+        assert (got == want).all()
+        # every depth is invalid -> 2000 everywhere
+        assert np.allclose(got[3], (2000.0 - mean[7]) / std[7])
+
+
+def test_more_crops_than_one_launch_holds(se3):
+    """se3tn_preprocess chunks the descriptors into kernel-argument blocks of 24."""
+    rng = np.random.default_rng(2)
+    rgb = torch.from_numpy(rng.integers(0, 256, (200, 260, 3), dtype=np.uint8)).cuda()
+    depth = torch.from_numpy(rng.integers(300, 1500, (200, 260)).astype(np.uint16).view(np.int16)).cuda()
+    eng = se3.Engine(0, 64)
+    mean, std = Fx.mean_std(0)
+    eng.set_normalization(mean, std)
+    n = 53
+    out = torch.empty((n, 176, 176, 4), device="cuda")
+    wins = [(int(i * 3 - 20), int(10 - i), int(i * 3 + 150), int(180 - i)) for i in range(n)]
+    eng.preprocess([dict(rgb=rgb, depth=depth, window=w, z_offset_mm=600.0 + i, stats=i & 1) for i, w in enumerate(wins)], out)
+    r, d = rgb.cpu().numpy(), depth.cpu().numpy().view(np.uint16)
+    for i in (0, 23, 24, 47, 48, 52):
+        want = _oracle_crop(r, d, wins[i], 600.0 + i, mean, std, i & 1)
+        assert (out[i].permute(2, 0, 1).cpu().numpy() == want).all(), i
+
+
+def test_external_nhwc_equals_nchw_and_internal_buffers(se3):
+    sd = O.make_state_dict(0)
+    eng = se3.Engine(0, 4)
+    eng.load_state_dict(sd)
+    A, B = Fx.net_inputs(21, 4)
+    t1 = torch.empty((4, 3), device="cuda"); r1 = torch.empty((4, 3), device="cuda")
+    t2 = torch.empty_like(t1); r2 = torch.empty_like(r1)
+    eng.infer(A.cuda(), B.cuda(), 4, se3.NCHW, t1, r1)
+    eng.infer(A.permute(0, 2, 3, 1).contiguous().cuda(), B.permute(0, 2, 3, 1).contiguous().cuda(), 4, se3.NHWC, t2, r2)
+    assert (t1 == t2).all() and (r1 == r2).all()
+    ref = O.forward(sd, A, B)
+    assert float((t1.cpu() - ref["trans"]).abs().max()) < 1e-4
+
+
+def test_batch_equals_max_batch_and_over(se3):
+    sd = O.make_state_dict(0)
+    m = se3.Se3TrackNet(176, max_batch=3)
+    m.load_state_dict(sd); m.cuda(0)
+    A, B = Fx.net_inputs(8, 4)
+    out = m(A[:3].cuda(), B[:3].cuda())
+    ref = O.forward(sd, A[:3], B[:3])
+    assert float((out["rot"].cpu() - ref["rot"]).abs().max()) < 1e-4
+    assert float((out["feature"].cpu() - ref["feature"]).abs().max()) < 5e-6 * float(ref["feature"].abs().max())
+    with pytest.raises(se3._lib.Se3tnError):  # n > max_batch is refused, not truncated
+        m(A.cuda(), B.cuda())
+
+
+def test_error_paths_on_device_context(se3):
+    eng = se3.Engine(0, 1)
+    A = torch.zeros((1, 4, 176, 176), device="cuda")
+    with pytest.raises(se3._lib.Se3tnError, match="weights"):
+        eng.infer(A, A, 1, se3.NCHW)          # no weights bound
+    with pytest.raises(se3._lib.Se3tnError, match="normalization"):
+        eng.preprocess([dict(rgb=torch.zeros((4, 4, 3), dtype=torch.uint8, device="cuda"),
+                             depth=torch.zeros((4, 4), dtype=torch.int16, device="cuda"),
+                             window=(0, 0, 4, 4), z_offset_mm=0.0, stats=0)], torch.empty((1, 176, 176, 4), device="cuda"))
+    eng.set_normalization(np.zeros(8), np.ones(8))
+    with pytest.raises(se3._lib.Se3tnError, match="crop"):  # empty window
+        eng.preprocess([dict(rgb=torch.zeros((4, 4, 3), dtype=torch.uint8, device="cuda"),
+                             depth=torch.zeros((4, 4), dtype=torch.int16, device="cuda"),
+                             window=(2, 2, 2, 5), z_offset_mm=0.0, stats=0)], torch.empty((1, 176, 176, 4), device="cuda"))
+    eng.load_state_dict(O.make_state_dict(0))
+    lib = se3._lib.load()
+    rc = lib.se3tn_infer(eng._h, C.c_void_p(A.data_ptr()), C.c_void_p(A.data_ptr()), 1, 0, None, None,
+                         C.c_void_p(A.data_ptr()), None, None)
+    assert rc == -1  # poseA without poseB
+    blob = torch.zeros(eng.packed_bytes(), dtype=torch.uint8, device="cuda")
+    with pytest.raises(se3._lib.Se3tnError, match="header"):  # a blob that is not ours
+        eng.bind_blob(blob)
+
+
+class _Render:
+    def render(self, ob2cam, K, window):
+        return Fx.synthetic_render(7, ob2cam[2, 3])
+
+
+def test_tracker_samples_gt_1_and_bind_blob_path(se3):
+    """samples>1: the reference evaluates identical hypotheses and returns the first
+    (predict.py:229-231,294-296); weights arriving through the multi-GPU bind path give the same pose."""
+    sd = O.make_state_dict(0, head_gain=0.002)
+    mean, std = Fx.mean_std(0)
+    trk = se3.Tracker(Fx.DATASET_INFO, mean, std, {"state_dict": sd}, renderer=_Render(), max_samples=4)
+    rgb, depth = Fx.synthetic_frame(40)
+    P0 = Fx.pose(3)
+    P1 = trk.on_track(P0, rgb, depth, samples=1)
+    P4 = trk.on_track(P0, rgb, depth, samples=4)
+    assert (P1 == P4).all()
+    want, _ = O.on_track(sd, P0, rgb, depth, *Fx.synthetic_render(7, P0[2, 3]), Fx.K_YCB, 250.0, mean, std)
+    assert np.abs(P1 - want).max() < 1e-5
+    # same weights through pack -> (device copy standing in for the RCCL broadcast) -> bind
+    eng2 = se3.Engine(0, 1)
+    blob = se3.Engine(-1, 1).pack_state_dict(sd).cuda()
+    eng2.bind_blob(blob)
+    A, B = Fx.net_inputs(4, 1)
+    t_a = torch.empty((1, 3), device="cuda"); t_b = torch.empty((1, 3), device="cuda")
+    eng2.infer(A.cuda(), B.cuda(), 1, se3.NCHW, t_a, None)
+    trk.engine.infer(A.cuda(), B.cuda(), 1, se3.NCHW, t_b, None)
+    assert (t_a == t_b).all()
