@@ -10,7 +10,9 @@ from .engine import Engine, NCHW, NHWC, compute_bbox as compute_bbox_c, pose_upd
 from .se3_tracknet import Se3TrackNet
 from .tracker import Tracker
 from .utils import compute_bbox, crop_window
+from . import metrics, sequence
 
 _lib.load()
 
-__all__ = ["Engine", "Se3TrackNet", "Tracker", "compute_bbox", "crop_window", "pose_update_host", "NCHW", "NHWC"]
+__all__ = ["Engine", "Se3TrackNet", "Tracker", "compute_bbox", "crop_window", "pose_update_host", "NCHW", "NHWC",
+           "metrics", "sequence"]

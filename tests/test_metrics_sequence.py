@@ -1,0 +1,95 @@
+"""Metrics (CPU, known answers from the reference's own VOCap measured in SURVEY.md section 4) and the
+headless sequence driver (GPU, synthetic sequence in the reference's directory layout)."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import fixtures as Fx
+from oracle import se3_oracle as O
+
+
+@pytest.fixture(scope="module")
+def se3():
+    import se3tracknet_amd
+    return se3tracknet_amd
+
+
+def test_vocap_known_answers(se3):
+    V = se3.metrics.VOCap
+    assert V(np.zeros(10)) == pytest.approx(1.0, abs=1e-12)
+    assert V(np.full(10, 0.05)) == pytest.approx(0.55, abs=1e-12)
+    assert V(np.linspace(0, 0.2, 101)) == pytest.approx(0.2621782178217822, abs=1e-12)
+    with pytest.raises(IndexError):
+        V(np.full(5, 0.5))
+
+
+def test_vocap_matches_reference_source_when_available(se3):
+    from oracle import ref_shims
+    if not ref_shims.reference_available():
+        pytest.skip("reference tree not present")
+    import importlib.util, sys, types
+    ref_shims.install()
+    for m in ("matplotlib", "matplotlib.pyplot"):  # eval_ycb imports pyplot at module level
+        sys.modules.setdefault(m, types.ModuleType(m))
+    spec = importlib.util.spec_from_file_location("ref_eval_ycb", os.path.join(ref_shims.REFERENCE_ROOT, "eval_ycb.py"))
+    try:
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    except Exception as e:  # noqa
+        pytest.skip("reference eval_ycb not importable here: %r" % (e,))
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        errs = rng.exponential(0.03, 200)
+        assert se3.metrics.VOCap(errs) == mod.VOCap(errs)
+
+
+def test_add_adi_vs_brute_force(se3):
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-0.05, 0.05, (400, 3))
+    P, G = Fx.pose(1), Fx.pose(2)
+    a = pts @ P[:3, :3].T + P[:3, 3]; b = pts @ G[:3, :3].T + G[:3, 3]
+    assert se3.metrics.add(P, G, pts) == pytest.approx(np.linalg.norm(a - b, axis=1).mean(), abs=1e-15)
+    brute = np.sqrt(((b[:, None, :] - a[None, :, :]) ** 2).sum(-1)).min(1).mean()
+    assert se3.metrics.adi(P, G, se3.utils.PointCloud(pts)) == pytest.approx(brute, abs=1e-12)
+    assert se3.metrics.adi(P, P, pts) == 0.0 and se3.metrics.add(P, P, pts) == 0.0
+
+
+class _Render:
+    def render(self, ob2cam, K, window):
+        return Fx.synthetic_render(11, ob2cam[2, 3])
+
+
+@pytest.mark.gpu
+def test_sequence_driver_on_synthetic_ycb_layout(se3, tmp_path):
+    seq = tmp_path / "0048"
+    for d in ("color", "depth_filled", "pose_gt/4"):
+        os.makedirs(seq / d)
+    P = Fx.pose(3)
+    n = 6
+    for i in range(n):
+        rgb, depth = Fx.synthetic_frame(60 + i)
+        Image.fromarray(rgb).save(seq / "color" / ("%06d.png" % i))
+        Image.fromarray(depth).save(seq / "depth_filled" / ("%06d.png" % i))
+        np.savetxt(seq / "pose_gt/4" / ("%06d.txt" % i), P)
+    sd = O.make_state_dict(0, head_gain=0.0005)
+    mean, std = Fx.mean_std(0)
+    ply = tmp_path / "m.ply"
+    pts = np.random.default_rng(0).uniform(-0.04, 0.04, (300, 3))
+    with open(ply, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 300\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+        f.writelines("%.8f %.8f %.8f\n" % tuple(p) for p in pts)
+    info = dict(Fx.DATASET_INFO); info.pop("object_width")
+    trk = se3.Tracker(info, mean, std, {"state_dict": sd}, model_path=str(ply), renderer=_Render())
+    assert 80 < trk.object_width < 200  # 1.1 x hull diameter of an 8 cm cube cloud, in mm
+    out = tmp_path / "out"
+    res = se3.sequence.predict_sequence_ycb(trk, str(seq), 4, str(out) + "/")
+    assert res["frames"] == n - 1 and res["poses"].shape == (n, 4, 4) and res["hz"] > 50
+    assert sorted(os.listdir(out))[:2] == ["00000.txt", "00000gt.txt"] and len(os.listdir(out)) == 2 * n
+    assert np.allclose(np.loadtxt(out / "00000.txt"), P)
+    assert np.allclose(np.loadtxt(out / ("%05d.txt" % (n - 1))), res["poses"][-1])
+    # replay frame 1 through the oracle: same pose
+    rgb1, depth1 = Fx.synthetic_frame(61)
+    want, _ = O.on_track(sd, P, rgb1, depth1, *Fx.synthetic_render(11, P[2, 3]), Fx.K_YCB, trk.object_width, mean, std)
+    assert np.abs(res["poses"][1] - want).max() < 1e-5
+    assert 0.0 <= res["adi_auc"] <= 100.0 and len(res["adi_errs"]) == n
