@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--stage", default="full", choices=["full", "net"],
                     help="full = preprocess + network + pose update (default); net = network + pose on "
                          "pre-normalised NHWC pairs")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+                    help="f32 = exact float32 MFMA (default, the parity configuration); f16x3 = split-f16 MFMA for the "
+                         "256/512-channel layers (float32-class error, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch time breakdown to stderr")
     args = ap.parse_args()
@@ -73,6 +76,8 @@ def main():
     mean = np.array([110., 105., 100., 1000., 112., 104., 99., 1010.]); std = np.array([60., 58., 61., 300., 59., 60., 62., 310.])
     eng.set_normalization(mean, std)
     eng.set_normalizers(0.03, 5 * np.pi / 180)
+    if args.precision == "f16x3":
+        eng.set_precision(se3._lib.PREC_F16X3)
 
     # ---- synthetic inputs, resident in HBM (seeded per rank) -------------------------------
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -139,6 +144,7 @@ def main():
     layers = eng.profile_launches(slots - 1)
     eng.profile_enable(0)
     assert os.environ.get("SE3TN_NOCHECK") or torch.isfinite(poseB).all()
+    assert not eng.overflow(), "f16x3 range guard fired"
 
     if rank == 0:
         value = world * nb * args.steps / dt
@@ -146,7 +152,7 @@ def main():
             "metric": "RGB-D pair inferences/sec (176x176)", "value": round(value, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "configs[1]: batch=%d synthetic 176x176 RGB-D pairs per GPU, random-init Se3TrackNet "
                                    "(reference state_dict surface), stage=%s" % (nb, args.stage),
                        "pairs_per_gpu": nb, "global_batch": world * nb, "stage": args.stage,

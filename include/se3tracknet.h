@@ -69,6 +69,17 @@ int se3tn_bind_weights(se3tn_ctx* ctx, const void* device_blob, size_t bytes);
 /* ---- per-dataset constants --------------------------------------------------------------- */
 /* mean.npy / std.npy: float64[8] = A(R,G,B,D), B(R,G,B,D) (predict.py:657-658). */
 int se3tn_set_normalization(se3tn_ctx* ctx, const double mean[8], const double std[8]);
+/* Arithmetic of the 256/512-channel convolutions (72 % of the FLOPs) when n >= 32:
+ *   SE3TN_PREC_F32   (default) exact float32 MFMA everywhere;
+ *   SE3TN_PREC_F16X3 operands split into f16 hi + f16 lo (22 significant bits), products formed as
+ *                    hi*hi + hi*lo + lo*hi on the f16 matrix cores with float32 accumulation:
+ *                    float32-class error (measured ~1e-6 on the outputs) at 16/3 the MFMA rate.
+ *                    Activations of those layers must stay inside the f16 range (|x| < 65000);
+ *                    se3tn_overflow reports (and clears) a violation -- rerun in SE3TN_PREC_F32 then. */
+#define SE3TN_PREC_F32 0
+#define SE3TN_PREC_F16X3 1
+int se3tn_set_precision(se3tn_ctx* ctx, int mode);
+int se3tn_overflow(se3tn_ctx* ctx, int* flag); /* synchronises */
 /* trans_normalizer / rot_normalizer of Tracker.__init__ (predict.py:128). */
 int se3tn_set_normalizers(se3tn_ctx* ctx, double trans_normalizer, double rot_normalizer);
 

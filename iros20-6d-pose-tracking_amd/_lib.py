@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SE3TN_LIB") or os.path.join(_HERE, "libse3tracknet.so")
 
 NCHW, NHWC = 0, 1
+PREC_F32, PREC_F16X3 = 0, 1
 RES = 176
 
 
@@ -39,6 +40,8 @@ _SIGS = {
     "se3tn_upload_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se3tn_bind_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "se3tn_set_normalization": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "se3tn_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "se3tn_overflow": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "se3tn_set_normalizers": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "se3tn_preprocess": (C.c_int, [C.c_void_p, C.POINTER(Crop), C.c_int, C.c_void_p, C.c_void_p]),
     "se3tn_input_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),

@@ -43,9 +43,15 @@ struct se3tn_ctx {
   float *pool = nullptr, *t64 = nullptr, *q64 = nullptr;  // [mb,46,46,128]
   float *ab = nullptr, *ab_t = nullptr;         // [mb,24,24,256]
   float *head = nullptr, *head_t = nullptr;     // [mb,13,13,1024]
+  float* head_f = nullptr;                      // f16x3 mode: float32 output of the last head conv (the
+                                                // in-place residual update cannot change format)
+  const float* head_final = nullptr;            // what the tail of the last infer read
   float* logits = nullptr;                      // [mb,6]
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
   size_t part_bytes = 0;
+  int prec = SE3TN_PREC_F32;                    // se3tn_set_precision
+  bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
+  int* overflow = nullptr;                      // device flag: a split-row store left the f16 range
   double mean[8], stdv[8];
   bool have_norm = false;
   double tn = 0.03, rn = 5.0 * 3.14159265358979323846 / 180.0;
@@ -63,7 +69,7 @@ struct se3tn_ctx {
 
 extern "C" {
 
-const char* se3tn_version(void) { return "se3tracknet-gfx950 0.2.0 (blob v3)"; }
+const char* se3tn_version(void) { return "se3tracknet-gfx950 0.3.0 (blob v4)"; }
 const char* se3tn_last_error(void) { return g_err.c_str(); }
 
 int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
@@ -93,6 +99,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
         {&c->t64, padded(S2, 128), true},      {&c->q64, padded(S2, 128), true},
         {&c->ab, padded(S3, 256), true},       {&c->ab_t, padded(S3, 256), true},
         {&c->head, padded(S4, 1024), true},    {&c->head_t, padded(S4, 1024), true},
+        {&c->head_f, padded(S4, 1024), true},
         {&c->logits, mb * 6, true}};
     for (auto& b : bufs) {
       e = hipMalloc((void**)b.p, b.words * sizeof(float));
@@ -105,6 +112,9 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
     c->part_bytes = (size_t)16 * 1024 * 121 * 16 * sizeof(float);
     e = hipMalloc((void**)&c->part, c->part_bytes);
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(split-K workspace)"); }
+    e = hipMalloc((void**)&c->overflow, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->overflow, 0, sizeof(int));
+    if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(overflow flag)"); }
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipDeviceSynchronize"); }
   }
@@ -116,9 +126,10 @@ void se3tn_destroy(se3tn_ctx* c) {
   if (!c) return;
   if (c->device >= 0) {
     float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
-                     c->head_t, c->logits, c->part, c->blob_owned};
+                     c->head_t, c->head_f, c->logits, c->part, c->blob_owned};
     for (float* b : bufs)
       if (b) (void)hipFree(b);
+    if (c->overflow) (void)hipFree(c->overflow);
     for (int s = 0; s < c->slots; ++s)
       for (auto& e : c->evs[s]) (void)hipEventDestroy(e);
   }
@@ -184,6 +195,19 @@ int se3tn_set_normalization(se3tn_ctx* c, const double mean[8], const double std
   std::memcpy(c->mean, mean, sizeof(c->mean));
   std::memcpy(c->stdv, stdv, sizeof(c->stdv));
   c->have_norm = true;
+  return SE3TN_OK;
+}
+
+int se3tn_set_precision(se3tn_ctx* c, int mode) {
+  if (!c || (mode != SE3TN_PREC_F32 && mode != SE3TN_PREC_F16X3)) return fail(SE3TN_E_ARG, "se3tn_set_precision: bad mode");
+  c->prec = mode;
+  return SE3TN_OK;
+}
+
+int se3tn_overflow(se3tn_ctx* c, int* flag) {
+  if (!c || c->device < 0 || !flag) return fail(SE3TN_E_ARG, "se3tn_overflow: bad argument");
+  HIPCHK(hipMemcpy(flag, c->overflow, sizeof(int), hipMemcpyDeviceToHost));
+  if (*flag) HIPCHK(hipMemset(c->overflow, 0, sizeof(int)));
   return SE3TN_OK;
 }
 
@@ -257,11 +281,19 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
   HIPCHK(launch_maxpool(c->stem, c->pool, n, st));
   HIPCHK((hipError_t)prof_mark(c, st, "maxpool3x3s2", false));
 
+  // f16x3 mode applies to the throughput regime only (the small-batch split-K path stays float32)
+  const bool fast = c->prec == SE3TN_PREC_F16X3 && n >= 32;
+  c->last_fast = fast;
   auto conv = [&](ConvId id, const float* in, int in_ld, int in_gs, const float* res, int res_ld, int res_gs,
                   float* out, int out_ld, int out_gs, int hin, int stride, int epi, const char* name) -> int {
     const Conv3& s = conv_specs()[id];
     ConvArgs a{};
-    a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id]; a.res = res; a.out = out; a.part = c->part; a.part_bytes = c->part_bytes;
+    a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id];
+    if (fast && id >= LAB1) {
+      a.fast = 1;
+      a.overflow = c->overflow;
+      if (id >= LAB2_1) { a.w = W + L.conv_ws[id]; a.wscale = W + L.conv_sc[id]; }
+    } a.res = res; a.out = out; a.part = c->part; a.part_bytes = c->part_bytes;
     a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
     a.H = hin; a.W = hin; a.Ho = (hin - 1) / stride + 1; a.Wo = a.Ho;
     a.M = n * a.Ho * a.Wo;
@@ -283,9 +315,11 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
   if ((rc = conv(LAB2_2, c->ab_t, 256, 0, c->ab, 256, 0, c->ab, 256, 0, S3, 1, 1, "convAB2.conv2"))) return rc;
   if ((rc = conv(LH1, c->ab, 256, 0, nullptr, 0, 0, c->head, 1024, 0, S3, 2, 2, "trans|rot conv1 s2"))) return rc;
   if ((rc = conv(LH2_1, c->head, 1024, 512, nullptr, 0, 0, c->head_t, 1024, 512, S4, 1, 0, "trans|rot conv2.conv1"))) return rc;
-  if ((rc = conv(LH2_2, c->head_t, 1024, 512, c->head, 1024, 512, c->head, 1024, 512, S4, 1, 1, "trans|rot conv2.conv2"))) return rc;
+  float* head_out = fast ? c->head_f : c->head;
+  if ((rc = conv(LH2_2, c->head_t, 1024, 512, c->head, 1024, 512, head_out, 1024, 512, S4, 1, 1, "trans|rot conv2.conv2"))) return rc;
+  c->head_final = head_out;
 
-  HIPCHK(launch_tail(c->head, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st));
+  HIPCHK(launch_tail(head_out, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st));
   HIPCHK((hipError_t)prof_mark(c, st, "tail avgpool+fc+tanh+pose", false));
   if (c->prof) c->slot_launches[slot] = c->n_launch;
   return SE3TN_OK;
@@ -293,7 +327,7 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
 
 int se3tn_get_feature(se3tn_ctx* c, int n, float* feature_nchw, void* stream) {
   if (!c || c->device < 0 || !feature_nchw || n < 1 || n > c->max_batch) return fail(SE3TN_E_ARG, "se3tn_get_feature: bad argument");
-  HIPCHK(launch_padded_nhwc_to_nchw(c->ab, feature_nchw, n, S3, S3, 256, (hipStream_t)stream));
+  HIPCHK(launch_padded_nhwc_to_nchw(c->ab, feature_nchw, n, S3, S3, 256, c->last_fast ? 1 : 0, (hipStream_t)stream));
   return SE3TN_OK;
 }
 
@@ -305,7 +339,7 @@ int se3tn_debug_buffer(se3tn_ctx* c, const char* name, const float** ptr, int32_
       {"inA", c->inA, IN_P, IN_P, 4},    {"inB", c->inB, IN_P, IN_P, 4},     {"stem", c->stem, S1, S1, 128},
       {"pool", c->pool, S2 + 2, S2 + 2, 128},    {"t64", c->t64, S2 + 2, S2 + 2, 128},
       {"q64", c->q64, S2 + 2, S2 + 2, 128},      {"ab", c->ab, S3 + 2, S3 + 2, 256},
-      {"ab_t", c->ab_t, S3 + 2, S3 + 2, 256},    {"head", c->head, S4 + 2, S4 + 2, 1024},
+      {"ab_t", c->ab_t, S3 + 2, S3 + 2, 256},    {"head", c->head_final ? c->head_final : c->head, S4 + 2, S4 + 2, 1024},
       {"head_t", c->head_t, S4 + 2, S4 + 2, 1024}};
   for (auto& e : t)
     if (std::strcmp(e.n, name) == 0) {

@@ -43,6 +43,22 @@
 namespace se3tn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+// Arithmetic modes of the MFMA core (template parameter MM)
+//   MM_F32   v_mfma_f32_32x32x2_f32 on float32 operands: bitwise an fmaf chain (default).
+//   MM_F16X3 operands stored as "split rows": per (pixel | cout, 32-channel chunk) 128 bytes =
+//            32 x f16 hi | 32 x f16 lo with x = hi + lo to 22 significant bits; the product is formed
+//            as hi*hi + hi*lo + lo*hi with three v_mfma_f32_32x32x16_f16 (f32 accumulate): 16/3 = 5.3x
+//            the f32 MFMA rate at f32-class error (the dropped lo*lo term is 2^-22 relative).
+//            A split row has the SAME size, 16-byte slot structure and swizzle as a float32 row:
+//            slots 0-3 = hi channels 0-31, slots 4-7 = lo, and slot 2 kb + hh (+4) is exactly the
+//            8-half MFMA operand of lane-half hh for 16-channel block kb -- i.e. the four 8-k groups
+//            of the f32 kernel ARE (hi kb0, hi kb1, lo kb0, lo kb1).
+enum { MM_F32 = 0, MM_F16X3 = 1 };
+// tensor element formats of the epilogue (template parameters OUTF / RESF)
+enum { FMT_F32 = 0, FMT_SPLIT = 1 };
 
 constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
 constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
@@ -53,12 +69,9 @@ __device__ __forceinline__ float selu_f(float v) {
 
 // EPI: 0 = bias+ReLU, 1 = bias+residual+ReLU, 2 = bias+SELU
 template <int EPI>
-__device__ __forceinline__ float4 apply_epilogue(float4 v, const float4 b, const float* res) {
+__device__ __forceinline__ float4 apply_epilogue(float4 v, const float4 b, const float4 r) {
   v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-  if (EPI == 1) {
-    const float4 r = *reinterpret_cast<const float4*>(res);
-    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-  }
+  if (EPI == 1) { v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
   if (EPI == 2) {
     v.x = selu_f(v.x); v.y = selu_f(v.y); v.z = selu_f(v.z); v.w = selu_f(v.w);
   } else {
@@ -116,6 +129,59 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[j].w, pv_[i].w, acc[i][j], 0, 0, 0);    \
   }
 
+// MM_F16X3: all four groups' fragments, then per 16-channel block kb: Whi*Phi + Whi*Plo + Wlo*Phi.
+// PVEXPR(G) / WVEXPR(G): float4 fragment of group G (may use `i` / `j`).
+#define SE3TN_MMA_SPLIT(PTN, CTN, PVEXPR, WVEXPR)                                                    \
+  {                                                                                                  \
+    half8 ph_[4][PTN], wh_[4][CTN];                                                                  \
+    _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                               \
+      _Pragma("unroll") for (int i = 0; i < PTN; ++i) {                                              \
+        const float4 t_ = PVEXPR(gq);                                                                \
+        ph_[gq][i] = __builtin_bit_cast(half8, t_);                                                  \
+      }                                                                                              \
+      _Pragma("unroll") for (int j = 0; j < CTN; ++j) {                                              \
+        const float4 t_ = WVEXPR(gq);                                                                \
+        wh_[gq][j] = __builtin_bit_cast(half8, t_);                                                  \
+      }                                                                                              \
+    }                                                                                                \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                               \
+      _Pragma("unroll") for (int j = 0; j < CTN; ++j) _Pragma("unroll") for (int i = 0; i < PTN; ++i) \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[kb][j], ph_[kb][i], acc[i][j], 0, 0, 0);     \
+      _Pragma("unroll") for (int j = 0; j < CTN; ++j) _Pragma("unroll") for (int i = 0; i < PTN; ++i) \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[kb][j], ph_[kb + 2][i], acc[i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int j = 0; j < CTN; ++j) _Pragma("unroll") for (int i = 0; i < PTN; ++i) \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[kb + 2][j], ph_[kb][i], acc[i][j], 0, 0, 0); \
+    }                                                                                                \
+  }
+
+// ---- split-row element access: 4 consecutive channels c..c+3 (c % 4 == 0) of pixel `pix` ---------
+__device__ __forceinline__ size_t split_byte_off(size_t pix, int ld, int c) {
+  return (pix * ld) * 4 + (size_t)(c >> 5) * 128 + (c & 31) * 2;
+}
+__device__ __forceinline__ float4 load_split4(const float* base, size_t pix, int ld, int c) {
+  const unsigned char* p_ = reinterpret_cast<const unsigned char*>(base) + split_byte_off(pix, ld, c);
+  const half4 h = *reinterpret_cast<const half4*>(p_);
+  const half4 l = *reinterpret_cast<const half4*>(p_ + 64);
+  return make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
+                     (float)h[3] + (float)l[3]);
+}
+// returns true if a value is outside the f16 range (the caller raises the overflow flag)
+__device__ __forceinline__ bool store_split4(float* base, size_t pix, int ld, int c, float4 v) {
+  unsigned char* p_ = reinterpret_cast<unsigned char*>(base) + split_byte_off(pix, ld, c);
+  half4 h, l;
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  bool bad = false;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (_Float16)f[e];
+    l[e] = (_Float16)(f[e] - (float)h[e]);
+    bad |= !(fabsf(f[e]) <= 65000.f);
+  }
+  *reinterpret_cast<half4*>(p_) = h;
+  *reinterpret_cast<half4*>(p_ + 64) = l;
+  return bad;
+}
+
 // padded-flat pixel index of interior pixel m (flattened over the batch) of an [n,H+2,W+2,*] tensor
 __device__ __forceinline__ int padded_index(int m, int HW, int W) {
   const int n = m / HW, rem = m - n * HW;
@@ -123,13 +189,16 @@ __device__ __forceinline__ int padded_index(int m, int HW, int W) {
   return (n * (HW / W + 2) + h + 1) * (W + 2) + w + 1;
 }
 
-// shared epilogue: lane holds pixel l31 x couts {8q + 4hh + 0..3} of each 32x32 tile
-template <int PT, int CT, int EPI>
+// shared epilogue: lane holds pixel l31 x couts {8q + 4hh + 0..3} of each 32x32 tile.
+// MM_F16X3 accumulators carry the per-cout power-of-two weight scale: acc * wscale[c] first.
+template <int PT, int CT, int EPI, int MM, int OUTF, int RESF>
 __device__ __forceinline__ void store_tiles(const ConvArgs& a, int g, const f32x16 (&acc)[PT][CT],
                                             const int (&opix)[PT], const bool (&ok)[PT], int cbase, int hh) {
   const float* __restrict__ bias = a.bias + (size_t)g * a.bias_gs;
+  const float* __restrict__ wsc = (MM == MM_F16X3) ? a.wscale + (size_t)g * a.bias_gs : nullptr;
   const float* __restrict__ res = (EPI == 1) ? a.res + (size_t)g * a.res_gs : nullptr;
   float* __restrict__ out = a.out + (size_t)g * a.out_gs;
+  bool bad = false;
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     if (!ok[i]) continue;
@@ -140,19 +209,29 @@ __device__ __forceinline__ void store_tiles(const ConvArgs& a, int g, const f32x
         const int c = cbase + j * 32 + q * 8 + hh * 4;
         float4 v = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
                                acc[i][j][4 * q + 3]);
+        if (MM == MM_F16X3) {
+          const float4 w = *reinterpret_cast<const float4*>(wsc + c);
+          v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
+        }
         const float4 b = *reinterpret_cast<const float4*>(bias + c);
-        v = apply_epilogue<EPI>(v, b, (EPI == 1) ? res + (size_t)opix[i] * a.res_ld + c : nullptr);
-        *reinterpret_cast<float4*>(out + (size_t)opix[i] * a.out_ld + c) = v;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == 1)
+          r = (RESF == FMT_SPLIT) ? load_split4(res, (size_t)opix[i], a.res_ld, c)
+                                  : *reinterpret_cast<const float4*>(res + (size_t)opix[i] * a.res_ld + c);
+        v = apply_epilogue<EPI>(v, b, r);
+        if (OUTF == FMT_SPLIT) bad |= store_split4(out, (size_t)opix[i], a.out_ld, c, v);
+        else *reinterpret_cast<float4*>(out + (size_t)opix[i] * a.out_ld + c) = v;
       }
     }
   }
+  if (OUTF == FMT_SPLIT && bad) atomicOr(a.overflow, 1);
 }
 
 // =================================================================================================
 // stride 1: slab kernel.  8 waves = WM x WN; wave tile = PT x CT tiles of 32x32.
 // LDS: [slab 0][slab 1][weights 0][weights 1], slab = SLABPX pixel rows of 32 floats.
 // =================================================================================================
-template <int CIN, int WM, int WN, int PT, int CT, int SLABPX, int EPI>
+template <int CIN, int WM, int WN, int PT, int CT, int SLABPX, int EPI, int MM, int OUTF, int RESF>
 __global__ __launch_bounds__(512, 2) void conv3x3_slab_kernel(const ConvArgs a) {
   constexpr int BM = WM * PT * 32, BN = WN * CT * 32;
   constexpr int NCH = CIN / 32;
@@ -270,26 +349,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_slab_kernel(const ConvArgs a) 
         py[i] = (hh ^ ((idx >> 1) & 7)) << 2;
       }
       const float* pW = smem + 2 * SLAB + wb * WT + (wn * CT * 32 + l31) * 32;
-      SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(smem + prow[i] + (0 ^ py[i])),
-                      *reinterpret_cast<const float4*>(pW + j * 1024 + fo0))
-      SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(smem + prow[i] + (8 ^ py[i])),
-                      *reinterpret_cast<const float4*>(pW + j * 1024 + fo1))
-      SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(smem + prow[i] + (16 ^ py[i])),
-                      *reinterpret_cast<const float4*>(pW + j * 1024 + fo2))
-      SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(smem + prow[i] + (24 ^ py[i])),
-                      *reinterpret_cast<const float4*>(pW + j * 1024 + fo3))
+#define PXF(G) *reinterpret_cast<const float4*>(smem + prow[i] + ((8 * (G)) ^ py[i]))
+#define WTF(G) *reinterpret_cast<const float4*>(pW + j * 1024 + ((G) == 0 ? fo0 : (G) == 1 ? fo1 : (G) == 2 ? fo2 : fo3))
+      if (MM == MM_F16X3) {
+        SE3TN_MMA_SPLIT(PT, CT, PXF, WTF)
+      } else {
+        SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
+        SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
+        SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
+        SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
+      }
+#undef PXF
+#undef WTF
       if (kt + 1 < NCH * 9) wait_dma_and_barrier();
     }
   }
 #undef SLAB_PIECE
 #undef WEIGHT_TILE
-  store_tiles<PT, CT, EPI>(a, g, acc, opix, ok, n0 + wn * CT * 32, hh);
+  store_tiles<PT, CT, EPI, MM, OUTF, RESF>(a, g, acc, opix, ok, n0 + wn * CT * 32, hh);
 }
 
 // =================================================================================================
 // stride 2: gather kernel, 4 waves = 2 x 2, wave tile 2 x 2 tiles (128 px x 128 cout), 2 WGs per CU
 // =================================================================================================
-template <int CIN, int EPI>
+template <int CIN, int EPI, int MM, int OUTF>
 __global__ __launch_bounds__(256, 2) void conv3x3_gather_s2_kernel(const ConvArgs a) {
   constexpr int BM = 128, BN = 128, PT = 2, CT = 2;
   constexpr int NCH = CIN / 32, KT = NCH * 9;
@@ -365,14 +448,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gather_s2_kernel(const ConvArg
     if (kt + 1 < KT) ISSUE_TILE(ch, tap, buf ^ 1)
     const float* pP = smem + buf * BUF + (wm * PT * 32 + l31) * 32;
     const float* pW = smem + buf * BUF + (BM + wn * CT * 32 + l31) * 32;
-    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo0),
-                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo0))
-    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo1),
-                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo1))
-    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo2),
-                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo2))
-    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo3),
-                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo3))
+#define FOG(G) ((G) == 0 ? fo0 : (G) == 1 ? fo1 : (G) == 2 ? fo2 : fo3)
+#define PXF(G) *reinterpret_cast<const float4*>(pP + i * 1024 + FOG(G))
+#define WTF(G) *reinterpret_cast<const float4*>(pW + j * 1024 + FOG(G))
+    if (MM == MM_F16X3) {
+      SE3TN_MMA_SPLIT(PT, CT, PXF, WTF)
+    } else {
+      SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
+      SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
+      SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
+      SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
+    }
+#undef PXF
+#undef WTF
+#undef FOG
     if (kt + 1 < KT) wait_dma_and_barrier();
   }
 #undef ISSUE_TILE
@@ -385,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gather_s2_kernel(const ConvArg
     ok[i] = m < a.M;
     opix[i] = padded_index(ok[i] ? m : mlast, HoWo, a.Wo);
   }
-  store_tiles<PT, CT, EPI>(a, g, acc, opix, ok, n0 + wn * CT * 32, hh);
+  store_tiles<PT, CT, EPI, MM, OUTF, FMT_F32>(a, g, acc, opix, ok, n0 + wn * CT * 32, hh);
 }
 
 // =================================================================================================
@@ -517,7 +606,9 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvArgs a, int 
   }
   const int opix = padded_index(m, a.Ho * a.Wo, a.Wo);
   const float4 b = *reinterpret_cast<const float4*>(a.bias + (size_t)g * a.bias_gs + c);
-  v = apply_epilogue<EPI>(v, b, (EPI == 1) ? a.res + (size_t)g * a.res_gs + (size_t)opix * a.res_ld + c : nullptr);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI == 1) r = *reinterpret_cast<const float4*>(a.res + (size_t)g * a.res_gs + (size_t)opix * a.res_ld + c);
+  v = apply_epilogue<EPI>(v, b, r);
   *reinterpret_cast<float4*>(a.out + (size_t)g * a.out_gs + (size_t)opix * a.out_ld + c) = v;
 }
 
@@ -531,12 +622,13 @@ static hipError_t set_lds(K kern, size_t lds, bool& done) {
   return e;
 }
 
-template <int CIN, int WM, int WN, int PT, int CT, int SLABPX, int EPI>
+template <int CIN, int WM, int WN, int PT, int CT, int SLABPX, int EPI, int MM = MM_F32, int OUTF = FMT_F32,
+          int RESF = FMT_F32>
 static hipError_t launch_slab(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = WM * PT * 32, BN = WN * CT * 32;
   constexpr size_t lds = (size_t)(2 * SLABPX * 32 + 2 * BN * 32) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv3x3_slab_kernel<CIN, WM, WN, PT, CT, SLABPX, EPI>;
+  auto kern = conv3x3_slab_kernel<CIN, WM, WN, PT, CT, SLABPX, EPI, MM, OUTF, RESF>;
   static bool attr = false;
   hipError_t e = set_lds(kern, lds, attr);
   if (e != hipSuccess) return e;
@@ -545,10 +637,10 @@ static hipError_t launch_slab(const ConvArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int CIN, int EPI>
+template <int CIN, int EPI, int MM = MM_F32, int OUTF = FMT_F32>
 static hipError_t launch_gather(const ConvArgs& a, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * 256 * 32 * sizeof(float);
-  auto kern = conv3x3_gather_s2_kernel<CIN, EPI>;
+  auto kern = conv3x3_gather_s2_kernel<CIN, EPI, MM, OUTF>;
   static bool attr = false;
   hipError_t e = set_lds(kern, lds, attr);
   if (e != hipSuccess) return e;
@@ -598,7 +690,7 @@ static int pick_slices(const ConvArgs& a, int cin, int cout, int big_tile_rows, 
 //   W = 44: 454 -> 464     W = 22: 378 -> 384     W = 11: 410 -> 424
 hipError_t launch_conv3x3(const ConvArgs& a0, int cin, int cout, int stride, int epi, hipStream_t st) {
   ConvArgs a = a0;
-  a.slices = pick_slices(a, cin, cout, stride == 1 ? 256 : 128, cout >= 128 ? 128 : 64);
+  a.slices = a.fast ? 0 : pick_slices(a, cin, cout, stride == 1 ? 256 : 128, cout >= 128 ? 128 : 64);
   if (a.slices > 0) {
     a.tiles_n = cout >= 128 ? cout / 128 : 1;
     if (cin == 64 && stride == 1) return launch_splitk<64, 1, 1>(a, epi, st);
@@ -606,6 +698,23 @@ hipError_t launch_conv3x3(const ConvArgs& a0, int cin, int cout, int stride, int
     if (cin == 256 && stride == 1) return launch_splitk<256, 1, 2>(a, epi, st);
     if (cin == 256 && stride == 2) return launch_splitk<256, 2, 2>(a, epi, st);
     if (cin == 512 && stride == 1) return launch_splitk<512, 1, 2>(a, epi, st);
+    return hipErrorInvalidValue;
+  }
+  if (a.fast) {
+    // f16x3 mode (se3tn_set_precision): the 256/512-channel layers run on the f16 matrix cores with
+    // split-row operands; convAB1 (f32 MFMA) produces the first split-row tensor, the last conv of
+    // the heads writes float32 for the tail.  a.fast: 1 = split in / split out, 2 = split in / f32 out.
+    a.tiles_n = cout / 128;
+    if (stride == 2 && cin == 128 && epi == 2) return launch_gather<128, 2, MM_F32, FMT_SPLIT>(a, st);
+    if (stride == 2 && cin == 256 && epi == 2) return launch_gather<256, 2, MM_F16X3, FMT_SPLIT>(a, st);
+    if (stride == 1 && cin == 256 && a.W == 22 && epi == 0)
+      return launch_slab<256, 4, 2, 2, 2, 384, 0, MM_F16X3, FMT_SPLIT, FMT_F32>(a, st);
+    if (stride == 1 && cin == 256 && a.W == 22 && epi == 1)
+      return launch_slab<256, 4, 2, 2, 2, 384, 1, MM_F16X3, FMT_SPLIT, FMT_SPLIT>(a, st);
+    if (stride == 1 && cin == 512 && a.W == 11 && epi == 0)
+      return launch_slab<512, 4, 2, 2, 2, 424, 0, MM_F16X3, FMT_SPLIT, FMT_F32>(a, st);
+    if (stride == 1 && cin == 512 && a.W == 11 && epi == 1)
+      return launch_slab<512, 4, 2, 2, 2, 424, 1, MM_F16X3, FMT_F32, FMT_SPLIT>(a, st);
     return hipErrorInvalidValue;
   }
   if (stride == 1 && cin == 64 && cout == 64 && a.W == 44) {

@@ -176,18 +176,25 @@ hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void padded_nhwc_to_nchw_kernel(const float* __restrict__ in,
                                                                    float* __restrict__ out, int h, int w,
-                                                                   int c, int total) {
+                                                                   int c, int total, int split) {
   const int idx = blockIdx.x * 256 + threadIdx.x;  // output index (n, c, y, x)
   if (idx >= total) return;
   const int x = idx % w, t1 = idx / w;
   const int y = t1 % h, t2 = t1 / h;
   const int ch = t2 % c, n = t2 / c;
-  out[idx] = in[((size_t)(n * (h + 2) + y + 1) * (w + 2) + x + 1) * c + ch];
+  const size_t pix = (size_t)(n * (h + 2) + y + 1) * (w + 2) + x + 1;
+  if (split) {  // f16x3 mode: value = hi + lo
+    const _Float16* row = reinterpret_cast<const _Float16*>(in + pix * c + (ch >> 5) * 32);
+    out[idx] = (float)row[ch & 31] + (float)row[32 + (ch & 31)];
+  } else {
+    out[idx] = in[pix * c + ch];
+  }
 }
 
-hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, hipStream_t st) {
+hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, int split,
+                                      hipStream_t st) {
   const int total = n * h * w * c;
-  hipLaunchKernelGGL(padded_nhwc_to_nchw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, h, w, c, total);
+  hipLaunchKernelGGL(padded_nhwc_to_nchw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, h, w, c, total, split);
   return hipGetLastError();
 }
 

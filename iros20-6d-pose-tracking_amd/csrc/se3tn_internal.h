@@ -48,6 +48,10 @@ struct BlobLayout {
   size_t stem_b;   // [2][64]
   size_t conv_w[NUM_CONV3];
   size_t conv_b[NUM_CONV3];
+  // f16x3 mode (layers LAB2_1 .. LH2_2 only, 0 elsewhere): the same panels as "split rows"
+  // (32 x f16 hi | 32 x f16 lo of w * 2^k per cout) and the per-cout 2^-k
+  size_t conv_ws[NUM_CONV3];
+  size_t conv_sc[NUM_CONV3];
   size_t fc_w;     // [2 heads][3][512]
   size_t fc_b;     // [2][4] (3 used)
   size_t total;    // words, incl. the 64-word header
@@ -55,7 +59,7 @@ struct BlobLayout {
 
 constexpr int HEADER_WORDS = 64;
 constexpr uint32_t BLOB_MAGIC = 0x53453354u;  // 'SE3T'
-constexpr uint32_t BLOB_VERSION = 3;
+constexpr uint32_t BLOB_VERSION = 4;
 
 inline const Conv3* conv_specs() {
   static const Conv3 s[NUM_CONV3] = {
@@ -73,6 +77,10 @@ inline BlobLayout blob_layout() {
   for (int i = 0; i < NUM_CONV3; ++i) {
     L.conv_w[i] = o; o += conv3_words(s[i].cin, s[i].cout) * s[i].groups;
     L.conv_b[i] = o; o += (size_t)s[i].cout * s[i].groups;
+  }
+  for (int i = LAB2_1; i < NUM_CONV3; ++i) {
+    L.conv_ws[i] = o; o += conv3_words(s[i].cin, s[i].cout) * s[i].groups;
+    L.conv_sc[i] = o; o += (size_t)s[i].cout * s[i].groups;
   }
   L.fc_w = o; o += 2 * 3 * 512;
   L.fc_b = o; o += 2 * 4;
@@ -110,6 +118,11 @@ struct ConvArgs {
   float* part;
   size_t part_bytes;
   int slices;
+  // f16x3 mode: per-cout power-of-two weight scale (acc * wscale = true sum), overflow flag,
+  // fast = 0 (f32 everywhere) | 1 | 2 (see launch_conv3x3)
+  const float* wscale;
+  int* overflow;
+  int fast;
 };
 
 struct CropArgs {  // one launch handles up to MAX crops
@@ -134,7 +147,9 @@ hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, 
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,
                        double rn, int n, hipStream_t st);
 // padded [n,h+2,w+2,c] NHWC interior -> [n,c,h,w]
-hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, hipStream_t st);
+// split != 0: the source holds split rows (32 f16 hi | 32 f16 lo per 32-channel chunk)
+hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, int split,
+                                      hipStream_t st);
 
 // host-side packer (weights.cpp)
 struct HostTensor {

@@ -84,6 +84,69 @@ void pack3(const Folded& f, float* dst, int cout_total, int o_off) {
               f.w[(((size_t)o * f.cin) + ch * 32 + ci) * 9 + tap];
 }
 
+// float32 -> IEEE binary16 bits, round to nearest even (subnormals kept, overflow -> inf)
+uint16_t f32_to_f16_bits(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));  // inf / nan
+  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                     // rounds to inf
+  if (x < 0x38800000u) {                                                                        // subnormal / zero
+    if (x < 0x33000000u) return (uint16_t)sign;                                                 // < 2^-25
+    const int shift = 126 - (int)(x >> 23);  // 14..24: value = mant * 2^-(shift + 10)
+    const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+    uint32_t h = mant >> shift;
+    const uint32_t rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1))) ++h;
+    return (uint16_t)(sign | h);
+  }
+  uint32_t h = ((x >> 23) - 112) << 10 | ((x >> 13) & 0x3ffu);
+  const uint32_t rem = x & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+  return (uint16_t)(sign | h);
+}
+float f16_bits_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ffu;
+  uint32_t x;
+  if (e == 0) {
+    if (m == 0) { x = sign; }
+    else { float v = std::ldexp((float)m, -24); std::memcpy(&x, &v, 4); x |= sign; }
+  } else if (e == 31) { x = sign | 0x7f800000u | (m << 13); }
+  else { x = sign | ((e + 112) << 23) | (m << 13); }
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+
+// OIHW 3x3 -> split rows [chunk][tap][cout_total][32 f16 hi | 32 f16 lo] of w * 2^k(cout), k chosen
+// so that the largest |w| of the cout row sits near 2^10; inv_scale[o] = 2^-k
+void pack3_split(const Folded& f, float* dst, float* inv_scale, int cout_total, int o_off) {
+  const int nch = f.cin / 32;
+  const size_t per = (size_t)f.cin * 9;
+  uint16_t* d16 = reinterpret_cast<uint16_t*>(dst);
+  for (int o = 0; o < f.cout; ++o) {
+    float mx = 0.f;
+    for (size_t i = 0; i < per; ++i) mx = std::fmax(mx, std::fabs(f.w[o * per + i]));
+    int k = 0;
+    if (mx > 0.f) k = (int)std::floor(10.0 - std::log2((double)mx));
+    if (k > 40) k = 40;
+    if (k < -20) k = -20;
+    const float sc = std::ldexp(1.0f, k);
+    inv_scale[o + o_off] = std::ldexp(1.0f, -k);
+    for (int ch = 0; ch < nch; ++ch)
+      for (int tap = 0; tap < 9; ++tap) {
+        uint16_t* row = d16 + ((((size_t)ch * 9 + tap) * cout_total + (o + o_off)) * 32) * 2;
+        for (int ci = 0; ci < 32; ++ci) {
+          const float w = f.w[(((size_t)o * f.cin) + ch * 32 + ci) * 9 + tap] * sc;  // exact (power of 2)
+          const uint16_t hi = f32_to_f16_bits(w);
+          row[ci] = hi;
+          row[32 + ci] = f32_to_f16_bits(w - f16_bits_to_f32(hi));
+        }
+      }
+  }
+}
+
 // OIHW 7x7, Cin=4 -> [64][204]: k = pair*8 + half*4 + c, the (tap of half 0 | tap of half 1) pairs in
 // the order stem7x7_mfma.hip walks them: 21 in-row pairs (r,2j)|(r,2j+1), 3 column-6 pairs
 // (2j,6)|(2j+1,6), then (6,6)|zero.  k 200..203 pad the row to 816 bytes.
@@ -146,6 +209,9 @@ std::string pack_blob(const TensorMap& t, std::vector<float>& blob) {
     pack3(f, blob.data() + L.conv_w[s.id] + gw * s.group, s.cout_total, s.o_off);
     std::memcpy(blob.data() + L.conv_b[s.id] + (size_t)spec[s.id].cout * s.group + s.o_off, f.b.data(),
                 f.b.size() * sizeof(float));
+    if (s.id >= LAB2_1)
+      pack3_split(f, blob.data() + L.conv_ws[s.id] + gw * s.group,
+                  blob.data() + L.conv_sc[s.id] + (size_t)spec[s.id].cout * s.group, s.cout_total, s.o_off);
   }
   const char* heads[2] = {"trans_out", "rot_out"};
   for (int h = 0; h < 2; ++h) {

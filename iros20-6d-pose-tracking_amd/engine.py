@@ -82,6 +82,16 @@ class Engine:
         s = (C.c_double * 8)(*[float(x) for x in np.asarray(std).reshape(8)])
         check(self.lib.se3tn_set_normalization(self._h, m, s), "se3tn_set_normalization")
 
+    def set_precision(self, mode):
+        """_lib.PREC_F32 (default, exact) or _lib.PREC_F16X3 (split-f16 MFMA for the deep layers, n >= 32)."""
+        check(self.lib.se3tn_set_precision(self._h, int(mode)), "se3tn_set_precision")
+
+    def overflow(self):
+        """True if a split-row store left the f16 range since the last call (synchronises)."""
+        f = C.c_int(0)
+        check(self.lib.se3tn_overflow(self._h, C.byref(f)), "se3tn_overflow")
+        return bool(f.value)
+
     def set_normalizers(self, trans_normalizer, rot_normalizer):
         check(self.lib.se3tn_set_normalizers(self._h, float(trans_normalizer), float(rot_normalizer)),
               "se3tn_set_normalizers")

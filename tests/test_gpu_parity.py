@@ -224,3 +224,45 @@ def test_tracker_on_track_vs_reference_golden(se3, golden_dir):
         assert np.abs(trk.last_prediction["rot"][0] - g["rot"][f]).max() < NET_TOL
         assert np.abs(P - g["poses"][f + 1]).max() < POSE_TOL, np.abs(P - g["poses"][f + 1]).max()
     assert trk.frame_cnt == 3
+
+
+def test_f16x3_mode_parity_and_overflow_guard(se3, model0):
+    """se3tn_set_precision(F16X3): the 256/512-channel layers run as hi*hi + hi*lo + lo*hi on the f16
+    matrix cores.  Same tolerances as the float32 path (measured error stays f32-class), identical
+    small-batch results (the latency path stays float32), and the range guard fires on overflow."""
+    model, sd = model0
+    eng = model.engine
+    A, B = Fx.net_inputs(17, 64)
+    Ac, Bc = A.cuda(), B.cuda()
+    o32 = model(Ac, Bc)
+    t32, r32, l32, f32 = o32["trans"].clone(), o32["rot"].clone(), eng.logits(64).clone(), o32["feature"].clone()
+    eng.set_precision(se3._lib.PREC_F16X3)
+    try:
+        o16 = model(Ac, Bc)
+        l16 = eng.logits(64)
+        assert not eng.overflow()
+        idx = [0, 31, 63]
+        ref = O.forward(sd, A[idx], B[idx], intermediates=True)
+        _close("f16x3 trans", o16["trans"][idx].cpu(), ref["trans"], 0, NET_TOL)
+        _close("f16x3 rot", o16["rot"][idx].cpu(), ref["rot"], 0, NET_TOL)
+        _close("f16x3 logits", l16[idx].cpu(), torch.cat([ref["trans_logit"], ref["rot_logit"]], 1), 0, NET_TOL)
+        _close("f16x3 feature (decoded split rows)", o16["feature"][idx].cpu(), ref["feature"], ACT_RTOL, 0, 5e-6)
+        head = _nchw(eng.debug_buffer("head", 64), 1)[idx]
+        _close("f16x3 trans_conv2", head[:, :512], ref["trans_c2"], ACT_RTOL, 0, 5e-6)
+        # how far the two arithmetic modes are from each other on the whole batch
+        d = float((l16 - l32).abs().max())
+        print("max |logit(f16x3) - logit(f32)| over 64 pairs = %.2e" % d)
+        assert d < 2e-5
+        assert float((o16["feature"] - f32).abs().max()) < 5e-6 * float(f32.abs().max()) + 1e-5
+        # n < 32: the split-K float32 path is used regardless of the mode -> bit-identical to PREC_F32
+        eng.set_precision(se3._lib.PREC_F32)
+        a = model(Ac[:4], Bc[:4], return_feature=False)["trans"].clone()
+        eng.set_precision(se3._lib.PREC_F16X3)
+        b = model(Ac[:4], Bc[:4], return_feature=False)["trans"].clone()
+        assert (a == b).all()
+        # range guard: activations beyond the f16 range are reported, not silently wrong
+        model(Ac * 3e4, Bc * 3e4, return_feature=False)
+        assert eng.overflow()
+        assert not eng.overflow()  # reading clears the flag
+    finally:
+        eng.set_precision(se3._lib.PREC_F32)

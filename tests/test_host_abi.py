@@ -98,6 +98,27 @@ def _numpy_pack(sd):
         else:
             f = [fold(c, b) for c, b in g]
             parts += [pack3(w) for w, _ in f] + [b for _, b in f]
+    # f16x3 sections: the deep layers again as split rows [chunk][tap][cout][32 f16 hi | 32 f16 lo] of
+    # w * 2^k(cout) plus the per-cout 2^-k
+    def pack3_split(w):
+        co, ci = w.shape[:2]
+        mx = np.abs(w).reshape(co, -1).max(1).astype(np.float64)
+        k = np.where(mx > 0, np.floor(10.0 - np.log2(np.where(mx > 0, mx, 1.0))), 0.0)
+        ws = (w.astype(np.float32) * np.exp2(k).astype(np.float32)[:, None, None, None])
+        hi = ws.astype(np.float16)
+        lo = (ws - hi.astype(np.float32)).astype(np.float16)
+        def rows(x):  # OIHW -> [chunk][tap][cout][32]
+            return x.reshape(co, ci // 32, 32, 9).transpose(1, 3, 0, 2)
+        both = np.concatenate([rows(hi), rows(lo)], axis=3)  # [..][64] halfs = 128 bytes
+        return np.ascontiguousarray(both).view(np.float32).reshape(-1), np.exp2(-k).astype(np.float32)
+    for g in groups[5:]:
+        if g == "H1":
+            (wt, _), (wr, _) = fold("trans_conv1.0", "trans_conv1.1"), fold("rot_conv1.0", "rot_conv1.1")
+            ws, sc = pack3_split(np.concatenate([wt, wr], 0))
+            parts += [ws, sc]
+        else:
+            f = [pack3_split(fold(c, b)[0]) for c, b in g]
+            parts += [x[0] for x in f] + [x[1] for x in f]
     for h in ("trans_out", "rot_out"):
         parts.append(sd[h + ".0.weight"].numpy().reshape(-1))
     for h in ("trans_out", "rot_out"):
@@ -114,7 +135,7 @@ def test_weight_folding_and_packing_host_only(se3):
     assert blob.size == want.size == eng.packed_bytes() // 4
     hdr = blob[:4].view(np.uint32)
     assert hdr[0] == 0x53453354 and hdr[2] == blob.size
-    assert (blob[64:] == want[64:]).all()
+    assert (blob[64:].view(np.uint32) == want[64:].view(np.uint32)).all()  # bit-exact incl. the f16 split rows
 
 
 def test_error_paths(se3):
