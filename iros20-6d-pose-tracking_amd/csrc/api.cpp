@@ -278,21 +278,22 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
   }
   HIPCHK(launch_stem(A, B, W + L.stem_w, W + L.stem_b, c->stem, n, st));
   HIPCHK((hipError_t)prof_mark(c, st, "stem7x7_mfma", false));
-  HIPCHK(launch_maxpool(c->stem, c->pool, n, st));
-  HIPCHK((hipError_t)prof_mark(c, st, "maxpool3x3s2", false));
-
   // f16x3 mode applies to the throughput regime only (the small-batch split-K path stays float32)
   const bool fast = c->prec == SE3TN_PREC_F16X3 && n >= 32;
   c->last_fast = fast;
+  HIPCHK(launch_maxpool(c->stem, c->pool, n, fast ? 1 : 0, st));
+  HIPCHK((hipError_t)prof_mark(c, st, "maxpool3x3s2", false));
+
   auto conv = [&](ConvId id, const float* in, int in_ld, int in_gs, const float* res, int res_ld, int res_gs,
                   float* out, int out_ld, int out_gs, int hin, int stride, int epi, const char* name) -> int {
     const Conv3& s = conv_specs()[id];
     ConvArgs a{};
     a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id];
-    if (fast && id >= LAB1) {
+    if (fast) {
       a.fast = 1;
       a.overflow = c->overflow;
-      if (id >= LAB2_1) { a.w = W + L.conv_ws[id]; a.wscale = W + L.conv_sc[id]; }
+      a.w = W + L.conv_ws[id];
+      a.wscale = W + L.conv_sc[id];
     } a.res = res; a.out = out; a.part = c->part; a.part_bytes = c->part_bytes;
     a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
     a.H = hin; a.W = hin; a.Ho = (hin - 1) / stride + 1; a.Wo = a.Ho;

@@ -701,11 +701,16 @@ hipError_t launch_conv3x3(const ConvArgs& a0, int cin, int cout, int stride, int
     return hipErrorInvalidValue;
   }
   if (a.fast) {
-    // f16x3 mode (se3tn_set_precision): the 256/512-channel layers run on the f16 matrix cores with
-    // split-row operands; convAB1 (f32 MFMA) produces the first split-row tensor, the last conv of
-    // the heads writes float32 for the tail.  a.fast: 1 = split in / split out, 2 = split in / f32 out.
+    // f16x3 mode (se3tn_set_precision): every 3x3 conv runs on the f16 matrix cores with split-row
+    // operands; the max-pool produces the first split-row tensor, the last conv of the heads writes
+    // float32 for the tail.
+    if (stride == 1 && cin == 64 && cout == 64 && a.W == 44) {
+      a.tiles_n = 1;
+      if (epi == 0) return launch_slab<64, 8, 1, 1, 2, 464, 0, MM_F16X3, FMT_SPLIT, FMT_F32>(a, st);
+      if (epi == 1) return launch_slab<64, 8, 1, 1, 2, 464, 1, MM_F16X3, FMT_SPLIT, FMT_SPLIT>(a, st);
+    }
     a.tiles_n = cout / 128;
-    if (stride == 2 && cin == 128 && epi == 2) return launch_gather<128, 2, MM_F32, FMT_SPLIT>(a, st);
+    if (stride == 2 && cin == 128 && epi == 2) return launch_gather<128, 2, MM_F16X3, FMT_SPLIT>(a, st);
     if (stride == 2 && cin == 256 && epi == 2) return launch_gather<256, 2, MM_F16X3, FMT_SPLIT>(a, st);
     if (stride == 1 && cin == 256 && a.W == 22 && epi == 0)
       return launch_slab<256, 4, 2, 2, 2, 384, 0, MM_F16X3, FMT_SPLIT, FMT_F32>(a, st);

@@ -48,7 +48,7 @@ struct BlobLayout {
   size_t stem_b;   // [2][64]
   size_t conv_w[NUM_CONV3];
   size_t conv_b[NUM_CONV3];
-  // f16x3 mode (layers LAB2_1 .. LH2_2 only, 0 elsewhere): the same panels as "split rows"
+  // f16x3 mode: the same panels as "split rows"
   // (32 x f16 hi | 32 x f16 lo of w * 2^k per cout) and the per-cout 2^-k
   size_t conv_ws[NUM_CONV3];
   size_t conv_sc[NUM_CONV3];
@@ -59,7 +59,7 @@ struct BlobLayout {
 
 constexpr int HEADER_WORDS = 64;
 constexpr uint32_t BLOB_MAGIC = 0x53453354u;  // 'SE3T'
-constexpr uint32_t BLOB_VERSION = 4;
+constexpr uint32_t BLOB_VERSION = 5;
 
 inline const Conv3* conv_specs() {
   static const Conv3 s[NUM_CONV3] = {
@@ -78,7 +78,7 @@ inline BlobLayout blob_layout() {
     L.conv_w[i] = o; o += conv3_words(s[i].cin, s[i].cout) * s[i].groups;
     L.conv_b[i] = o; o += (size_t)s[i].cout * s[i].groups;
   }
-  for (int i = LAB2_1; i < NUM_CONV3; ++i) {
+  for (int i = 0; i < NUM_CONV3; ++i) {
     L.conv_ws[i] = o; o += conv3_words(s[i].cin, s[i].cout) * s[i].groups;
     L.conv_sc[i] = o; o += (size_t)s[i].cout * s[i].groups;
   }
@@ -140,7 +140,8 @@ hipError_t launch_to_padded_input(const float* in, float* out, int n, int nchw, 
 hipError_t launch_preprocess(const CropArgs& a, hipStream_t st);
 hipError_t launch_stem(const float* inA, const float* inB, const float* w, const float* bias,
                        float* out, int n, hipStream_t st);
-hipError_t launch_maxpool(const float* in, float* out, int n, hipStream_t st);
+// split_out != 0: write split rows (f16 hi | f16 lo) for the f16x3 mode
+hipError_t launch_maxpool(const float* in, float* out, int n, int split_out, hipStream_t st);
 // conv3x3: cin/cout/stride select the instantiation; epi: 0 bias+relu, 1 bias+res+relu, 2 bias+selu
 hipError_t launch_conv3x3(const ConvArgs& a, int cin, int cout, int stride, int epi, hipStream_t st);
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,

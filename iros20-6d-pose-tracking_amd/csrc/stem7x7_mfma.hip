@@ -246,7 +246,7 @@ hipError_t launch_stem(const float* inA, const float* inB, const float* w, const
 // [n,46,46,128] tensor the 64-channel convs read; the pool's own padding is -inf (never wins), so
 // its input keeps explicit bounds.  One thread per (output pixel, 4 channels).
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ in,
-                                                            float* __restrict__ out, int total) {
+                                                            float* __restrict__ out, int total, int split_out) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int c4 = idx & 31;
@@ -266,12 +266,25 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
       m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
     }
   }
-  *reinterpret_cast<float4*>(out + ((size_t)(n * (S2 + 2) + po + 1) * (S2 + 2) + qo + 1) * 128 + c4 * 4) = m;
+  float* dst = out + ((size_t)(n * (S2 + 2) + po + 1) * (S2 + 2) + qo + 1) * 128;
+  if (split_out) {  // f16x3 mode: 32-channel chunk = 32 f16 hi | 32 f16 lo (SELU output is bounded below, finite)
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    const int c = c4 * 4;
+    unsigned char* p_ = reinterpret_cast<unsigned char*>(dst) + (c >> 5) * 128 + (c & 31) * 2;
+    const float f[4] = {m.x, m.y, m.z, m.w};
+    half4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = (_Float16)f[e]; l[e] = (_Float16)(f[e] - (float)h[e]); }
+    *reinterpret_cast<half4*>(p_) = h;
+    *reinterpret_cast<half4*>(p_ + 64) = l;
+  } else {
+    *reinterpret_cast<float4*>(dst + c4 * 4) = m;
+  }
 }
 
-hipError_t launch_maxpool(const float* in, float* out, int n, hipStream_t st) {
+hipError_t launch_maxpool(const float* in, float* out, int n, int split_out, hipStream_t st) {
   const int total = n * S2 * S2 * 32;
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, total);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, total, split_out);
   return hipGetLastError();
 }
 

@@ -209,8 +209,7 @@ std::string pack_blob(const TensorMap& t, std::vector<float>& blob) {
     pack3(f, blob.data() + L.conv_w[s.id] + gw * s.group, s.cout_total, s.o_off);
     std::memcpy(blob.data() + L.conv_b[s.id] + (size_t)spec[s.id].cout * s.group + s.o_off, f.b.data(),
                 f.b.size() * sizeof(float));
-    if (s.id >= LAB2_1)
-      pack3_split(f, blob.data() + L.conv_ws[s.id] + gw * s.group,
+    pack3_split(f, blob.data() + L.conv_ws[s.id] + gw * s.group,
                   blob.data() + L.conv_sc[s.id] + (size_t)spec[s.id].cout * s.group, s.cout_total, s.o_off);
   }
   const char* heads[2] = {"trans_out", "rot_out"};

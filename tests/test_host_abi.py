@@ -111,7 +111,7 @@ def _numpy_pack(sd):
             return x.reshape(co, ci // 32, 32, 9).transpose(1, 3, 0, 2)
         both = np.concatenate([rows(hi), rows(lo)], axis=3)  # [..][64] halfs = 128 bytes
         return np.ascontiguousarray(both).view(np.float32).reshape(-1), np.exp2(-k).astype(np.float32)
-    for g in groups[5:]:
+    for g in groups:
         if g == "H1":
             (wt, _), (wr, _) = fold("trans_conv1.0", "trans_conv1.1"), fold("rot_conv1.0", "rot_conv1.1")
             ws, sc = pack3_split(np.concatenate([wt, wr], 0))
