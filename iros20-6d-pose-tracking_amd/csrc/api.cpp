@@ -50,6 +50,7 @@ struct se3tn_ctx {
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
   size_t part_bytes = 0;
   int prec = SE3TN_PREC_F32;                    // se3tn_set_precision
+  int in_split[2] = {0, 0};                     // pixel format currently held by inA / inB
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
   int* overflow = nullptr;                      // device flag: a split-row store left the f16 range
   double mean[8], stdv[8];
@@ -69,7 +70,7 @@ struct se3tn_ctx {
 
 extern "C" {
 
-const char* se3tn_version(void) { return "se3tracknet-gfx950 0.3.0 (blob v4)"; }
+const char* se3tn_version(void) { return "se3tracknet-gfx950 0.3.1 (blob v6)"; }
 const char* se3tn_last_error(void) { return g_err.c_str(); }
 
 int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
@@ -236,6 +237,10 @@ int se3tn_preprocess(se3tn_ctx* c, const se3tn_crop* crops, int n, float* out, v
     std::memcpy(a.c, crops + i0, sizeof(se3tn_crop) * a.n);
     // the context's own input buffers are zero-bordered [n,182,182,4]; anything else is plain NHWC
     a.padded = (out == c->inA || out == c->inB) ? 1 : 0;
+    // the context's input buffers hold split pixels in f16x3 mode (consumed by the f16 stem)
+    a.split = (a.padded && c->prec == SE3TN_PREC_F16X3) ? 1 : 0;
+    a.overflow = c->overflow;
+    if (a.padded) c->in_split[out == c->inA ? 0 : 1] = a.split;
     a.out = out + (size_t)i0 * (a.padded ? IN_P * IN_P : RES * RES) * 4;
     HIPCHK(launch_preprocess(a, (hipStream_t)stream));
   }
@@ -269,14 +274,27 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
     HIPCHK(hipEventRecord(c->ev[0], st));
   }
 
+  const int want_split = c->prec == SE3TN_PREC_F16X3 ? 1 : 0;
   if (A != c->inA || B != c->inB) {  // external tensors: copy into the zero-bordered input buffers
-    if (A != c->inA) HIPCHK(launch_to_padded_input(A, c->inA, n, layout == SE3TN_NCHW, st));
-    if (B != c->inB) HIPCHK(launch_to_padded_input(B, c->inB, n, layout == SE3TN_NCHW, st));
+    if (A != c->inA) {
+      HIPCHK(launch_to_padded_input(A, c->inA, n, layout == SE3TN_NCHW, want_split, c->overflow, st));
+      c->in_split[0] = want_split;
+    }
+    if (B != c->inB) {
+      HIPCHK(launch_to_padded_input(B, c->inB, n, layout == SE3TN_NCHW, want_split, c->overflow, st));
+      c->in_split[1] = want_split;
+    }
     HIPCHK((hipError_t)prof_mark(c, st, "to_padded_input", false));
     A = c->inA;
     B = c->inB;
   }
-  HIPCHK(launch_stem(A, B, W + L.stem_w, W + L.stem_b, c->stem, n, st));
+  if (c->in_split[0] != want_split || c->in_split[1] != want_split)
+    return fail(SE3TN_E_STATE, "se3tn_infer: the input buffers were filled under a different precision mode "
+                               "(call se3tn_set_precision before se3tn_preprocess)");
+  if (want_split)
+    HIPCHK(launch_stem(A, B, W + L.stem_ws, W + L.stem_b, W + L.stem_sc, c->stem, n, st));
+  else
+    HIPCHK(launch_stem(A, B, W + L.stem_w, W + L.stem_b, nullptr, c->stem, n, st));
   HIPCHK((hipError_t)prof_mark(c, st, "stem7x7_mfma", false));
   // f16x3 mode applies to the throughput regime only (the small-batch split-K path stays float32)
   const bool fast = c->prec == SE3TN_PREC_F16X3 && n >= 32;

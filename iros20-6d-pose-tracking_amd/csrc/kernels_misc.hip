@@ -11,9 +11,24 @@
 
 namespace se3tn {
 
+// f16x3 mode: a network-input pixel (R,G,B,D) is stored as 4 x f16 hi | 4 x f16 lo in the same 16 bytes
+__device__ __forceinline__ float4 split_pixel(float4 v, bool& bad) {
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  half8 h;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (_Float16)f[e];
+    h[4 + e] = (_Float16)(f[e] - (float)h[e]);
+    bad |= !(fabsf(f[e]) <= 65000.f);
+  }
+  return __builtin_bit_cast(float4, h);
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void to_padded_input_kernel(const float* __restrict__ in,
-                                                               float* __restrict__ out, int total, int nchw) {
+                                                               float* __restrict__ out, int total, int nchw,
+                                                               int split, int* overflow) {
   const int idx = blockIdx.x * 256 + threadIdx.x;  // (n, y, x)
   if (idx >= total) return;
   constexpr int HW = RES * RES;
@@ -26,12 +41,19 @@ __global__ __launch_bounds__(256) void to_padded_input_kernel(const float* __res
   } else {
     v = *reinterpret_cast<const float4*>(in + (size_t)idx * 4);
   }
+  if (split) {
+    bool bad = false;
+    v = split_pixel(v, bad);
+    if (bad) atomicOr(overflow, 1);
+  }
   *reinterpret_cast<float4*>(out + (((size_t)n * IN_P + y + IN_PAD) * IN_P + x + IN_PAD) * 4) = v;
 }
 
-hipError_t launch_to_padded_input(const float* in, float* out, int n, int nchw, hipStream_t st) {
+hipError_t launch_to_padded_input(const float* in, float* out, int n, int nchw, int split, int* overflow,
+                                  hipStream_t st) {
   const int total = n * RES * RES;
-  hipLaunchKernelGGL(to_padded_input_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, total, nchw);
+  hipLaunchKernelGGL(to_padded_input_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, total, nchw,
+                     split, overflow);
   return hipGetLastError();
 }
 
@@ -73,6 +95,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const CropArgs a) {
   o.w = (float)(((double)d - mean[3]) / sd[3]);
   float* dst = a.padded ? a.out + (((size_t)i * IN_P + y + IN_PAD) * IN_P + x + IN_PAD) * 4
                         : a.out + ((size_t)i * RES * RES + p) * 4;
+  if (a.split) {
+    bool bad = false;
+    o = split_pixel(o, bad);
+    if (bad) atomicOr(a.overflow, 1);
+  }
   *reinterpret_cast<float4*>(dst) = o;
 }
 

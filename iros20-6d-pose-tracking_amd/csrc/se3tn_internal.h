@@ -46,6 +46,8 @@ struct BlobLayout {
   // offsets in float32 words
   size_t stem_w;   // [2 branches][64][204]
   size_t stem_b;   // [2][64]
+  size_t stem_ws;  // f16x3: [2][64][204] words, each 16-byte (pair, half) entry = 4 f16 hi | 4 f16 lo
+  size_t stem_sc;  // f16x3: [2][64] per-cout 2^-k
   size_t conv_w[NUM_CONV3];
   size_t conv_b[NUM_CONV3];
   // f16x3 mode: the same panels as "split rows"
@@ -59,7 +61,7 @@ struct BlobLayout {
 
 constexpr int HEADER_WORDS = 64;
 constexpr uint32_t BLOB_MAGIC = 0x53453354u;  // 'SE3T'
-constexpr uint32_t BLOB_VERSION = 5;
+constexpr uint32_t BLOB_VERSION = 6;
 
 inline const Conv3* conv_specs() {
   static const Conv3 s[NUM_CONV3] = {
@@ -73,6 +75,8 @@ inline BlobLayout blob_layout() {
   size_t o = HEADER_WORDS;
   L.stem_w = o; o += (size_t)2 * 64 * 204;
   L.stem_b = o; o += 2 * 64;
+  L.stem_ws = o; o += (size_t)2 * 64 * 204;
+  L.stem_sc = o; o += 2 * 64;
   const Conv3* s = conv_specs();
   for (int i = 0; i < NUM_CONV3; ++i) {
     L.conv_w[i] = o; o += conv3_words(s[i].cin, s[i].cout) * s[i].groups;
@@ -132,14 +136,18 @@ struct CropArgs {  // one launch handles up to MAX crops
   float* out;   // plain [n,176,176,4], or (padded != 0) the interior of [n,182,182,4]
   int n;
   int padded;
+  int split;    // f16x3 mode: a pixel is stored as 4 x f16 hi | 4 x f16 lo (same 16 bytes)
+  int* overflow;
 };
 
 // launchers (defined in the .hip files)
 // NCHW [n,4,176,176] (nchw != 0) or plain NHWC [n,176,176,4] -> interior of the padded [n,182,182,4]
-hipError_t launch_to_padded_input(const float* in, float* out, int n, int nchw, hipStream_t st);
+hipError_t launch_to_padded_input(const float* in, float* out, int n, int nchw, int split, int* overflow,
+                                  hipStream_t st);
 hipError_t launch_preprocess(const CropArgs& a, hipStream_t st);
+// wscale != nullptr selects the f16x3 stem (split pixels, split weights w)
 hipError_t launch_stem(const float* inA, const float* inB, const float* w, const float* bias,
-                       float* out, int n, hipStream_t st);
+                       const float* wscale, float* out, int n, hipStream_t st);
 // split_out != 0: write split rows (f16 hi | f16 lo) for the f16x3 mode
 hipError_t launch_maxpool(const float* in, float* out, int n, int split_out, hipStream_t st);
 // conv3x3: cin/cout/stride select the instantiation; epi: 0 bias+relu, 1 bias+res+relu, 2 bias+selu

@@ -27,6 +27,8 @@
 namespace se3tn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
 constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
 __device__ __forceinline__ float selu_s(float v) {
@@ -47,9 +49,15 @@ struct StemArgs {
   const float* in[2];  // [n,182,182,4] per branch (zero border of 3)
   const float* w;      // [2][64][204]
   const float* bias;   // [2][64]
+  const float* wscale; // F16X3: [2][64] per-cout 2^-k
   float* out;          // [n,88,88,128]
   int n;
 };
+
+// F16X3 = 1: the same kernel on the f16 matrix cores.  A pixel is 4 x f16 hi | 4 x f16 lo (the same 16
+// bytes), a weight entry (pair, half-wave) is w_hi(4) | w_lo(4).  With B = [x_hi | x_lo] as loaded and
+// A1 = [w_hi | w_hi], A2 = [w_lo | 0] built in registers, two v_mfma_f32_32x32x16_f16 per tap pair give
+// w_hi x_hi + w_hi x_lo + w_lo x_hi for both taps (vs four f32 MFMAs of twice the cycles each).
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
@@ -70,6 +78,7 @@ __device__ __forceinline__ void dma1k(const float* base, unsigned voff, unsigned
       : "memory");
 }
 
+template <int F16X3>
 __global__ __launch_bounds__(512, 2) void stem7x7_slab_kernel(const StemArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [weights][slab 0][slab 1]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -121,6 +130,14 @@ __global__ __launch_bounds__(512, 2) void stem7x7_slab_kernel(const StemArgs a) 
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       bias_r[j][q] = *reinterpret_cast<const float4*>(a.bias + br * 64 + j * 32 + q * 8 + hh * 4);
+  float4 wsc_r[2][4];
+  if (F16X3) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        wsc_r[j][q] = *reinterpret_cast<const float4*>(a.wscale + br * 64 + j * 32 + q * 8 + hh * 4);
+  }
 
   auto epilogue = [&](const f32x16 (&acc)[2], float* __restrict__ out) {
 #pragma unroll
@@ -129,11 +146,13 @@ __global__ __launch_bounds__(512, 2) void stem7x7_slab_kernel(const StemArgs a) 
       for (int q = 0; q < 4; ++q) {
         const int c = j * 32 + q * 8 + hh * 4;
         const float4 b = bias_r[j][q];
+        float4 w = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (F16X3) w = wsc_r[j][q];
         float4 v;
-        v.x = selu_s(acc[j][4 * q + 0] + b.x);
-        v.y = selu_s(acc[j][4 * q + 1] + b.y);
-        v.z = selu_s(acc[j][4 * q + 2] + b.z);
-        v.w = selu_s(acc[j][4 * q + 3] + b.w);
+        v.x = selu_s(acc[j][4 * q + 0] * w.x + b.x);
+        v.y = selu_s(acc[j][4 * q + 1] * w.y + b.y);
+        v.z = selu_s(acc[j][4 * q + 2] * w.z + b.z);
+        v.w = selu_s(acc[j][4 * q + 3] * w.w + b.w);
 #if (SE3TN_STEM_ABLATE & 1)
         asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));  // timing ablation: no stores
 #else
@@ -185,8 +204,20 @@ __global__ __launch_bounds__(512, 2) void stem7x7_slab_kernel(const StemArgs a) 
       F##w0 = *reinterpret_cast<const float4*>(wl + k_ * 32);                                       \
       F##w1 = *reinterpret_cast<const float4*>(wl + 32 * WROW * 4 + k_ * 32);                       \
     }
-#define STEM_MMA(F)                                                                                 \
+#define STEM_MMA16(W, P, J)                                                                         \
     {                                                                                               \
+      const uint4v wu_ = __builtin_bit_cast(uint4v, W);                                             \
+      const uint4v a1_ = {wu_[0], wu_[1], wu_[0], wu_[1]};                                          \
+      const uint4v a2_ = {wu_[2], wu_[3], 0u, 0u};                                                  \
+      const half8 pb_ = __builtin_bit_cast(half8, P);                                               \
+      acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a1_), pb_, acc[J], 0, 0, 0); \
+      acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a2_), pb_, acc[J], 0, 0, 0); \
+    }
+#define STEM_MMA(F)                                                                                 \
+    if (F16X3) {                                                                                    \
+      STEM_MMA16(F##w0, F##p, 0)                                                                    \
+      STEM_MMA16(F##w1, F##p, 1)                                                                    \
+    } else {                                                                                        \
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##w0.x, F##p.x, acc[0], 0, 0, 0);              \
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##w1.x, F##p.x, acc[1], 0, 0, 0);              \
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##w0.y, F##p.y, acc[0], 0, 0, 0);              \
@@ -208,6 +239,7 @@ __global__ __launch_bounds__(512, 2) void stem7x7_slab_kernel(const StemArgs a) 
 #undef STEM_FENCE
 #undef STEM_STEP2
 #undef STEM_MMA
+#undef STEM_MMA16
 #undef STEM_LOAD
 
     float* out = ok ? a.out + ((size_t)img * S1 * S1 + p) * 128 + br * 64 : nullptr;
@@ -225,20 +257,24 @@ __global__ __launch_bounds__(512, 2) void stem7x7_slab_kernel(const StemArgs a) 
 }
 
 hipError_t launch_stem(const float* inA, const float* inB, const float* w, const float* bias,
-                       float* out, int n, hipStream_t st) {
+                       const float* wscale, float* out, int n, hipStream_t st) {
   constexpr size_t lds = WBYTES + 2 * SLAB_BYTES;  // 128,000 B
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7x7_slab_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7x7_slab_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7x7_slab_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr = true;
   }
   StemArgs a;
-  a.in[0] = inA; a.in[1] = inB; a.w = w; a.bias = bias; a.out = out; a.n = n;
+  a.in[0] = inA; a.in[1] = inB; a.w = w; a.bias = bias; a.wscale = wscale; a.out = out; a.n = n;
   const int ntiles = n * TILES_PER_IMAGE;
   const int per_branch = ntiles < 128 ? ntiles : 128;  // one workgroup per CU, half the chip per branch
-  hipLaunchKernelGGL(stem7x7_slab_kernel, dim3(2 * per_branch), dim3(512), lds, st, a);
+  if (wscale) hipLaunchKernelGGL(stem7x7_slab_kernel<1>, dim3(2 * per_branch), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(stem7x7_slab_kernel<0>, dim3(2 * per_branch), dim3(512), lds, st, a);
   return hipGetLastError();
 }
 

@@ -174,6 +174,32 @@ void pack_stem(const Folded& f, float* dst) {
       }
 }
 
+// f16x3 stem: same [64][204] geometry, every 16-byte (pair, half) entry = w_hi(c0..3) | w_lo(c0..3) of
+// w * 2^k(cout)
+void pack_stem_split(const Folded& f, float* dst, float* inv_scale) {
+  std::vector<float> plain((size_t)64 * 204);
+  pack_stem(f, plain.data());
+  uint16_t* d16 = reinterpret_cast<uint16_t*>(dst);
+  std::memset(dst, 0, sizeof(float) * 64 * 204);
+  for (int o = 0; o < 64; ++o) {
+    float mx = 0.f;
+    for (int k = 0; k < 200; ++k) mx = std::fmax(mx, std::fabs(plain[(size_t)o * 204 + k]));
+    int kx = 0;
+    if (mx > 0.f) kx = (int)std::floor(10.0 - std::log2((double)mx));
+    if (kx > 40) kx = 40;
+    if (kx < -20) kx = -20;
+    const float sc = std::ldexp(1.0f, kx);
+    inv_scale[o] = std::ldexp(1.0f, -kx);
+    for (int e = 0; e < 50; ++e)       // 25 pairs x 2 halves
+      for (int c = 0; c < 4; ++c) {
+        const float w = plain[(size_t)o * 204 + e * 4 + c] * sc;
+        const uint16_t hi = f32_to_f16_bits(w);
+        d16[((size_t)o * 204 + e * 4) * 2 + c] = hi;
+        d16[((size_t)o * 204 + e * 4) * 2 + 4 + c] = f32_to_f16_bits(w - f16_bits_to_f32(hi));
+      }
+  }
+}
+
 }  // namespace
 
 // returns "" on success, else the missing key / problem
@@ -190,6 +216,7 @@ std::string pack_blob(const TensorMap& t, std::vector<float>& blob) {
     Folded f = fold(t, std::string(stems[br]) + ".0", std::string(stems[br]) + ".1");
     pack_stem(f, blob.data() + L.stem_w + (size_t)br * 64 * 204);
     std::memcpy(blob.data() + L.stem_b + br * 64, f.b.data(), 64 * sizeof(float));
+    pack_stem_split(f, blob.data() + L.stem_ws + (size_t)br * 64 * 204, blob.data() + L.stem_sc + br * 64);
   }
   struct Src { ConvId id; int group; int o_off; int cout_total; const char* conv; const char* bn; };
   const Src srcs[] = {

@@ -76,6 +76,7 @@ def _numpy_pack(sd):
     stems = [fold(n + ".0", n + ".1") for n in ("convA1", "convB1")]
     pairs = [((r, 2 * sp), (r, 2 * sp + 1)) for r in range(7) for sp in range(3)]
     pairs += [((2 * j, 6), (2 * j + 1, 6)) for j in range(3)] + [((6, 6), None)]
+    stem_plain = []
     for w, _ in stems:  # [o][pair*8 + half*4 + c], row padded to 204
         t = np.zeros((64, 204), np.float32)
         for pi, pr in enumerate(pairs):
@@ -83,7 +84,19 @@ def _numpy_pack(sd):
                 if tap is not None:
                     t[:, pi * 8 + h * 4: pi * 8 + h * 4 + 4] = w[:, :, tap[0], tap[1]]
         parts.append(t.reshape(-1))
+        stem_plain.append(t)
     parts += [b for _, b in stems]
+    inv = []
+    for t in stem_plain:  # f16x3 stem: per 16-byte entry 4 f16 hi | 4 f16 lo of w * 2^k(cout)
+        mx = np.abs(t[:, :200]).max(1).astype(np.float64)
+        k = np.where(mx > 0, np.floor(10.0 - np.log2(np.where(mx > 0, mx, 1.0))), 0.0)
+        ws = t[:, :200] * np.exp2(k).astype(np.float32)[:, None]
+        hi = ws.astype(np.float16); lo = (ws - hi.astype(np.float32)).astype(np.float16)
+        e = np.concatenate([hi.reshape(64, 50, 4), lo.reshape(64, 50, 4)], axis=2).reshape(64, 400)
+        row = np.zeros((64, 408), np.float16); row[:, :400] = e
+        parts.append(np.ascontiguousarray(row).view(np.float32).reshape(-1))
+        inv.append(np.exp2(-k).astype(np.float32))
+    parts += inv
     groups = [[("convA2.conv1", "convA2.bn1"), ("convB2.conv1", "convB2.bn1")],
               [("convA2.conv2", "convA2.bn2"), ("convB2.conv2", "convB2.bn2")],
               [("convB3.conv1", "convB3.bn1")], [("convB3.conv2", "convB3.bn2")],
