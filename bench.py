@@ -217,9 +217,13 @@ def pmc_traffic(nb):
     # launches per step of each instantiation: 64-ch kernels run twice (grouped A|B pair + B3 alone)
     total = 0.0
     for k, v in d["fetch"].items():
-        if not k.startswith("conv3x3"):
+        if not k.startswith("conv3x3") or "<" not in k:
             continue
-        calls = 2 if "<64," in k else 1
+        targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
+        mm = targs[7] if k.startswith("conv3x3_slab") else targs[2]  # arithmetic mode template argument
+        if mm != "0":
+            continue  # the float32 instantiations only (the summary also holds the f16x3 ones)
+        calls = 2 if targs[0] == "64" else 1
         total += calls * (2.0 * v["FETCH_SIZE"] + d["write"][k]["WRITE_SIZE"]) * 1024.0
     return total, os.path.basename(files[-1])
 
