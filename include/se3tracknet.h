@@ -121,6 +121,21 @@ int se3tn_get_feature(se3tn_ctx* ctx, int n, float* feature_nchw, void* stream);
 /* pre-tanh FC outputs of the last se3tn_infer: device float32 [max_batch,6] (trans, rot) */
 const float* se3tn_logits(se3tn_ctx* ctx);
 
+/* ---- rendered image A: HIP rasteriser replacing the reference's OpenGL renderer ---------------- */
+/* vispy_renderer.py:47-178 (VispyRenderer) as called by Tracker.render_window (predict.py:193-215).
+ * Mesh = what the reference reads from the .ply: float32 vertices [V,3] (metres), unit vertex normals
+ * [V,3], vertex colours [V,3] already divided by 255, int32 triangles [F,3] (host pointers, copied). */
+typedef struct se3tn_mesh se3tn_mesh;
+int se3tn_mesh_create(se3tn_ctx* ctx, const float* verts, const float* normals, const float* colors01, int V,
+                      const int32_t* faces, int F, se3tn_mesh** out);
+void se3tn_mesh_destroy(se3tn_mesh* mesh);
+/* ob_in_cam: row-major 4x4 object pose in the OpenCV camera; K row-major 3x3; window = {left, top,
+ * right, bottom} as render_window derives it from compute_bbox(..., scale=(1000,-1000,1000))
+ * (predict.py:201-206: u range, and the range of the FLIPPED row coordinate cy - fy y/z).
+ * Outputs (device): rgb uint8 [176,176,3], depth uint16 [176,176] millimetres, 0 = background. */
+int se3tn_render(se3tn_ctx* ctx, se3tn_mesh* mesh, const double ob_in_cam[16], const double K[9],
+                 const int32_t window[4], uint8_t* rgb, uint16_t* depth, void* stream);
+
 /* ---- host-side pieces of the path (pure CPU, float64, as the reference computes them) ----- */
 /* Utils.py:302-316 compute_bbox with scale (1000,1000,1000): pose row-major 4x4 (metres), K
  * row-major 3x3, width in mm; out_vu[8] = 4 x (v,u) int32, np.round (half-to-even). */

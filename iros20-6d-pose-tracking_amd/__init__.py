@@ -11,8 +11,9 @@ from .se3_tracknet import Se3TrackNet
 from .tracker import Tracker
 from .utils import compute_bbox, crop_window
 from . import metrics, sequence
+from .renderer import HipRenderer
 
 _lib.load()
 
 __all__ = ["Engine", "Se3TrackNet", "Tracker", "compute_bbox", "crop_window", "pose_update_host", "NCHW", "NHWC",
-           "metrics", "sequence"]
+           "metrics", "sequence", "HipRenderer"]

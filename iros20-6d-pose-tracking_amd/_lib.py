@@ -49,6 +49,11 @@ _SIGS = {
                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "se3tn_get_feature": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "se3tn_logits": (C.c_void_p, [C.c_void_p]),
+    "se3tn_mesh_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.POINTER(C.c_void_p)]),
+    "se3tn_mesh_destroy": (None, [C.c_void_p]),
+    "se3tn_render": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                               C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p]),
     "se3tn_compute_bbox": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
                                      C.POINTER(C.c_int32)]),
     "se3tn_pose_update_host": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -53,6 +53,7 @@ struct se3tn_ctx {
   int in_split[2] = {0, 0};                     // pixel format currently held by inA / inB
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
   int* overflow = nullptr;                      // device flag: a split-row store left the f16 range
+  unsigned long long* zbuf = nullptr;           // rasteriser z-buffer keys [176*176]
   double mean[8], stdv[8];
   bool have_norm = false;
   double tn = 0.03, rn = 5.0 * 3.14159265358979323846 / 180.0;
@@ -66,6 +67,13 @@ struct se3tn_ctx {
   int slot_launches[MAX_SLOTS];
   const char* names[MAX_LAUNCHES];
   bool is_conv[MAX_LAUNCHES];
+};
+
+struct se3tn_mesh {
+  float *verts = nullptr, *normals = nullptr, *colors = nullptr;
+  int* faces = nullptr;
+  float4* vwin = nullptr;
+  int V = 0, F = 0;
 };
 
 extern "C" {
@@ -113,6 +121,8 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
     c->part_bytes = (size_t)16 * 1024 * 121 * 16 * sizeof(float);
     e = hipMalloc((void**)&c->part, c->part_bytes);
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(split-K workspace)"); }
+    e = hipMalloc((void**)&c->zbuf, sizeof(unsigned long long) * RES * RES);
+    if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(zbuf)"); }
     e = hipMalloc((void**)&c->overflow, sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->overflow, 0, sizeof(int));
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(overflow flag)"); }
@@ -131,6 +141,7 @@ void se3tn_destroy(se3tn_ctx* c) {
     for (float* b : bufs)
       if (b) (void)hipFree(b);
     if (c->overflow) (void)hipFree(c->overflow);
+    if (c->zbuf) (void)hipFree(c->zbuf);
     for (int s = 0; s < c->slots; ++s)
       for (auto& e : c->evs[s]) (void)hipEventDestroy(e);
   }
@@ -366,6 +377,58 @@ int se3tn_debug_buffer(se3tn_ctx* c, const char* name, const float** ptr, int32_
       return SE3TN_OK;
     }
   return fail(SE3TN_E_KEY, std::string("unknown buffer ") + name);
+}
+
+// ---- rasteriser: replaces VispyRenderer (vispy_renderer.py:47-178) on the per-frame path ---------
+int se3tn_mesh_create(se3tn_ctx* c, const float* verts, const float* normals, const float* colors01, int V,
+                      const int32_t* faces, int F, se3tn_mesh** out) {
+  if (!c || c->device < 0 || !verts || !normals || !colors01 || !faces || V < 3 || F < 1 || !out)
+    return fail(SE3TN_E_ARG, "se3tn_mesh_create: bad argument");
+  for (int i = 0; i < 3 * F; ++i)
+    if (faces[i] < 0 || faces[i] >= V) return fail(SE3TN_E_ARG, "se3tn_mesh_create: face index out of range");
+  se3tn_mesh* m = new se3tn_mesh();
+  m->V = V; m->F = F;
+  struct { void** p; const void* src; size_t bytes; } up[] = {
+      {(void**)&m->verts, verts, sizeof(float) * 3 * V},     {(void**)&m->normals, normals, sizeof(float) * 3 * V},
+      {(void**)&m->colors, colors01, sizeof(float) * 3 * V}, {(void**)&m->faces, faces, sizeof(int) * 3 * F},
+      {(void**)&m->vwin, nullptr, sizeof(float4) * V}};
+  for (auto& u : up) {
+    hipError_t e = hipMalloc(u.p, u.bytes);
+    if (e == hipSuccess && u.src) e = hipMemcpy(*u.p, u.src, u.bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { se3tn_mesh_destroy(m); return hipfail(e, "se3tn_mesh_create"); }
+  }
+  *out = m;
+  return SE3TN_OK;
+}
+
+void se3tn_mesh_destroy(se3tn_mesh* m) {
+  if (!m) return;
+  void* bufs[] = {m->verts, m->normals, m->colors, m->faces, m->vwin};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  delete m;
+}
+
+int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const double K[9], const int32_t window[4],
+                 uint8_t* rgb, uint16_t* depth, void* stream) {
+  if (!c || c->device < 0 || !m || !ob_in_cam || !K || !window || !rgb || !depth)
+    return fail(SE3TN_E_ARG, "se3tn_render: bad argument");
+  if (window[2] <= window[0] || window[3] <= window[1]) return fail(SE3TN_E_ARG, "se3tn_render: empty window");
+  RasterArgs a{};
+  a.verts = m->verts; a.normals = m->normals; a.colors = m->colors; a.faces = m->faces; a.vwin = m->vwin;
+  a.zbuf = c->zbuf; a.rgb = rgb; a.depth = depth; a.V = m->V; a.F = m->F;
+  for (int i = 0; i < 12; ++i) a.M[i] = (float)ob_in_cam[i];
+  a.fx = (float)K[0]; a.fy = (float)K[4]; a.cx = (float)K[2]; a.cy = (float)K[5];
+  a.left = (float)window[0]; a.top = (float)window[1]; a.right = (float)window[2]; a.bottom = (float)window[3];
+  // light_direction = (inv(ob2cam_gl^T) . [0, 0.1, -0.9, 1])[:3]  (vispy_renderer.py:172), float64 on the host.
+  // ob2cam_gl = diag(1,-1,-1,1) . ob_in_cam = [R' t'; 0 1];  inv(G^T) = (G^-1)^T = [R' 0; -t'^T R' 1]
+  // (G^-1 = [R'^T, -R'^T t'; 0 1]), so the first three components are R' . (0, 0.1, -0.9).
+  const double sgn[3] = {1.0, -1.0, -1.0};
+  const double l[3] = {0.0, 0.1, -0.9};
+  for (int r = 0; r < 3; ++r)
+    a.light[r] = (float)(sgn[r] * (ob_in_cam[4 * r] * l[0] + ob_in_cam[4 * r + 1] * l[1] + ob_in_cam[4 * r + 2] * l[2]));
+  HIPCHK(launch_raster(a, (hipStream_t)stream));
+  return SE3TN_OK;
 }
 
 int se3tn_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {

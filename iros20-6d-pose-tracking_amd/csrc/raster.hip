@@ -1,0 +1,159 @@
+// HIP rasteriser for the "rendered image A" of Tracker.render_window (predict.py:193-215), replacing
+// the reference's OpenGL renderer vispy_renderer.py:47-178.  It writes
+// rgbA (uint8 176x176x3) and depthA (uint16 mm) on the device, i.e. straight into the input of the
+// preprocessing kernel -- no GL context, no glReadPixels, no host round trip.
+//
+// What is restated from the reference (parity unpinned: a GL driver's sub-pixel snapping and
+// depth-buffer format are not observable offline):
+//   * vertex shader (:78-98): gl_Position = proj * view * vec4(pos,1) with
+//       view = diag(1,-1,-1,1) * ob_in_cv_cam,  proj = ortho(left,right,bottom,top) * K-projection
+//       (update_cam_mat :135-150, near 0.1 m, far 2.0 m) -- here folded analytically:
+//       X = fx x/z + cx,  Y = cy - fy y/z  (the window is given in these coordinates),  w = z;
+//   * fixed function: viewport 176x176, pixel centres at +0.5, top-left fill rule, depth test LESS
+//     against a cleared 1.0 (:153-156), depth affine in window space, other varyings
+//     perspective-correct.  NO face culling: the reference calls gloo.set_cull_face('back') (:155),
+//     which only selects glCullFace -- GL_CULL_FACE is never enabled (set_state(depth_test=True) only),
+//     and it could not be: the window's y axis is flipped by ortho(top<bottom), so "front" faces are
+//     clockwise here.  Both windings are rasterised and the depth test keeps the nearest surface;
+//   * fragment shader (:54-76): lightDir = normalize(-light_direction - fragpos) (object space),
+//       colour = clamp((0.4 max(dot(n, lightDir), 0) + 0.65) * vertexColour, 0, 1)  -> UNORM8;
+//   * read-back (:160-169): rows bottom-up (=> top-down in the OpenCV image), distance recovered from
+//     the depth buffer = camera z, background 0, depth_mm = uint16(z * 1000).
+//
+// Three kernels: vertices -> window space; one thread per triangle scatters (depth | triangle id) keys
+// with 64-bit atomicMin (deterministic z-buffer, ties broken by triangle index); one thread per pixel
+// re-derives the barycentrics of the winning triangle, interpolates and shades.
+#include "se3tn_internal.h"
+
+namespace se3tn {
+
+constexpr float R_NEAR = 0.1f, R_FAR = 2.0f;
+
+__global__ __launch_bounds__(256) void raster_vertex_kernel(const RasterArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.V) return;
+  const float px = a.verts[3 * i], py = a.verts[3 * i + 1], pz = a.verts[3 * i + 2];
+  const float x = a.M[0] * px + a.M[1] * py + a.M[2] * pz + a.M[3];
+  const float y = a.M[4] * px + a.M[5] * py + a.M[6] * pz + a.M[7];
+  const float z = a.M[8] * px + a.M[9] * py + a.M[10] * pz + a.M[11];
+  const float iw = 1.0f / z;  // clip w = z
+  const float X = a.fx * x * iw + a.cx, Y = a.cy - a.fy * y * iw;
+  const float xn = (2.f * X - a.right - a.left) / (a.right - a.left);
+  const float yn = (2.f * Y - a.top - a.bottom) / (a.top - a.bottom);
+  // z_ndc = -A + B / z with A = -(n+f)/(f-n), B = -2nf/(f-n)
+  const float A = -(R_NEAR + R_FAR) / (R_FAR - R_NEAR), B = -2.f * R_NEAR * R_FAR / (R_FAR - R_NEAR);
+  const float zn = -A + B * iw;
+  a.vwin[i] = make_float4((xn + 1.f) * (RES * 0.5f), (yn + 1.f) * (RES * 0.5f), (zn + 1.f) * 0.5f, z > 0.f ? iw : -1.f);
+}
+
+__device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by, float px, float py) {
+  return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+}
+// top-left rule for an edge a->b of a counter-clockwise triangle (y up): left edges go down, top edges
+// are horizontal and go left
+__device__ __forceinline__ bool top_left(float ax, float ay, float bx, float by) {
+  const float dx = bx - ax, dy = by - ay;
+  return dy < 0.f || (dy == 0.f && dx < 0.f);
+}
+
+__device__ __forceinline__ bool covers(const float4 v0, const float4 v1, const float4 v2, float area, float px,
+                                       float py, float& l0, float& l1, float& l2) {
+  const float e0 = edge_fn(v1.x, v1.y, v2.x, v2.y, px, py);
+  const float e1 = edge_fn(v2.x, v2.y, v0.x, v0.y, px, py);
+  const float e2 = edge_fn(v0.x, v0.y, v1.x, v1.y, px, py);
+  const bool in0 = e0 > 0.f || (e0 == 0.f && top_left(v1.x, v1.y, v2.x, v2.y));
+  const bool in1 = e1 > 0.f || (e1 == 0.f && top_left(v2.x, v2.y, v0.x, v0.y));
+  const bool in2 = e2 > 0.f || (e2 == 0.f && top_left(v0.x, v0.y, v1.x, v1.y));
+  const float ia = 1.0f / area;
+  l0 = e0 * ia; l1 = e1 * ia; l2 = e2 * ia;
+  return in0 && in1 && in2;
+}
+
+__global__ __launch_bounds__(256) void raster_triangle_kernel(const RasterArgs a) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.F) return;
+  const float4 v0 = a.vwin[a.faces[3 * t]];
+  float4 v1 = a.vwin[a.faces[3 * t + 1]], v2 = a.vwin[a.faces[3 * t + 2]];
+  if (v0.w <= 0.f || v1.w <= 0.f || v2.w <= 0.f) return;  // behind the camera: not clipped, dropped
+  float area = edge_fn(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+  if (area == 0.f || area != area) return;  // degenerate
+  if (area < 0.f) { const float4 tmp = v1; v1 = v2; v2 = tmp; area = -area; }  // orient counter-clockwise
+  const float xmin = fminf(v0.x, fminf(v1.x, v2.x)), xmax = fmaxf(v0.x, fmaxf(v1.x, v2.x));
+  const float ymin = fminf(v0.y, fminf(v1.y, v2.y)), ymax = fmaxf(v0.y, fmaxf(v1.y, v2.y));
+  const int i0 = max(0, (int)floorf(xmin - 0.5f)), i1 = min(RES - 1, (int)ceilf(xmax - 0.5f));
+  const int j0 = max(0, (int)floorf(ymin - 0.5f)), j1 = min(RES - 1, (int)ceilf(ymax - 0.5f));
+  for (int j = j0; j <= j1; ++j)
+    for (int i = i0; i <= i1; ++i) {
+      float l0, l1, l2;
+      if (!covers(v0, v1, v2, area, i + 0.5f, j + 0.5f, l0, l1, l2)) continue;
+      const float zw = l0 * v0.z + l1 * v1.z + l2 * v2.z;
+      if (!(zw >= 0.f && zw < 1.f)) continue;  // near / far planes; LESS against the cleared 1.0
+      const unsigned long long key = ((unsigned long long)__float_as_uint(zw) << 32) | (unsigned)t;
+      atomicMin(a.zbuf + j * RES + i, key);
+    }
+}
+
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const RasterArgs a) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= RES * RES) return;
+  // GL window row j counts bottom-up, and glReadPixels returns rows in that order; the reference
+  // reshapes the buffer as-is.  `bottom` is the LARGER Y = cy - fy y/z, i.e. the smaller OpenCV v, so
+  // array row j is already top-down in the OpenCV image: output index = window index.
+  const int j = p / RES, i = p - j * RES;
+  const unsigned long long key = a.zbuf[p];
+  uint8_t* rgb = a.rgb + (size_t)p * 3;
+  if (key == ~0ull) {
+    rgb[0] = 0; rgb[1] = 0; rgb[2] = 0;
+    a.depth[p] = 0;
+    return;
+  }
+  const int t = (int)(unsigned)key;
+  const int f0 = a.faces[3 * t];
+  int f1 = a.faces[3 * t + 1], f2 = a.faces[3 * t + 2];
+  const float4 v0 = a.vwin[f0];
+  float4 v1 = a.vwin[f1], v2 = a.vwin[f2];
+  float area = edge_fn(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+  if (area < 0.f) {  // same orientation as the scatter pass
+    const float4 tv = v1; v1 = v2; v2 = tv;
+    const int tf = f1; f1 = f2; f2 = tf;
+    area = -area;
+  }
+  float l0, l1, l2;
+  covers(v0, v1, v2, area, i + 0.5f, j + 0.5f, l0, l1, l2);
+  // perspective-correct weights
+  const float q0 = l0 * v0.w, q1 = l1 * v1.w, q2 = l2 * v2.w;
+  const float iq = 1.0f / (q0 + q1 + q2);
+  const float b0 = q0 * iq, b1 = q1 * iq, b2 = q2 * iq;
+  float pos[3], nrm[3], col[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    pos[c] = b0 * a.verts[3 * f0 + c] + b1 * a.verts[3 * f1 + c] + b2 * a.verts[3 * f2 + c];
+    nrm[c] = b0 * a.normals[3 * f0 + c] + b1 * a.normals[3 * f1 + c] + b2 * a.normals[3 * f2 + c];
+    col[c] = b0 * a.colors[3 * f0 + c] + b1 * a.colors[3 * f1 + c] + b2 * a.colors[3 * f2 + c];
+  }
+  float lx = -a.light[0] - pos[0], ly = -a.light[1] - pos[1], lz = -a.light[2] - pos[2];
+  const float il = rsqrtf(lx * lx + ly * ly + lz * lz);
+  lx *= il; ly *= il; lz *= il;
+  const float diff = 0.4f * fmaxf(nrm[0] * lx + nrm[1] * ly + nrm[2] * lz, 0.f) + 0.65f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = fminf(fmaxf(diff * col[c], 0.f), 1.f);
+    rgb[c] = (uint8_t)(int)rintf(v * 255.f);
+  }
+  // distance = B / (zw * -2 + 1 - A) * -1  (vispy_renderer.py:164-169) == camera z
+  const float zw = __uint_as_float((unsigned)(key >> 32));
+  const float A = -(R_NEAR + R_FAR) / (R_FAR - R_NEAR), B = -2.f * R_NEAR * R_FAR / (R_FAR - R_NEAR);
+  const float dist = B / (zw * -2.0f + 1.0f - A) * -1.0f;
+  a.depth[p] = (dist >= B / (A + 1.f)) ? (uint16_t)0 : (uint16_t)(dist * 1000.f);
+}
+
+hipError_t launch_raster(const RasterArgs& a, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(a.zbuf, 0xff, sizeof(unsigned long long) * RES * RES, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(raster_vertex_kernel, dim3((a.V + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(raster_triangle_kernel, dim3((a.F + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(raster_resolve_kernel, dim3((RES * RES + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace se3tn

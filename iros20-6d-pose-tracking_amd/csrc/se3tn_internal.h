@@ -160,6 +160,24 @@ hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, 
 hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, int split,
                                       hipStream_t st);
 
+// rasteriser (raster.hip)
+struct RasterArgs {
+  const float* verts;    // [V,3] object space
+  const float* normals;  // [V,3]
+  const float* colors;   // [V,3] in [0,1]
+  const int* faces;      // [F,3]
+  float4* vwin;          // [V] scratch: window-space x, y, depth in [0,1], 1/w
+  unsigned long long* zbuf;  // [176*176] scratch
+  uint8_t* rgb;          // out [176,176,3]
+  uint16_t* depth;       // out [176,176] millimetres
+  float M[12];           // ob_in_cv_cam rows 0..2 (R | t)
+  float fx, fy, cx, cy;
+  float left, right, top, bottom;  // window in (X, Y) coordinates, Y = cy - fy y / z
+  float light[3];        // light_direction in object space
+  int V, F;
+};
+hipError_t launch_raster(const RasterArgs& a, hipStream_t st);
+
 // host-side packer (weights.cpp)
 struct HostTensor {
   const float* data;

@@ -1,0 +1,67 @@
+"""HIP rasteriser front end: drop-in for the reference's VispyRenderer as used by
+Tracker.render_window (vispy_renderer.py:47-178, predict.py:193-215) -- no OpenGL.
+The rendered rgbA / depthA stay on the device and feed se3tn_preprocess directly."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import utils as U
+from ._lib import check
+from .engine import _stream_ptr
+
+
+class HipRenderer:
+    def __init__(self, engine, model, resolution=176):
+        """model: path to a .ply with faces / vertex colours / normals, or a dict with
+        vertices [V,3], faces [F,3], colors [V,3] (0..255), normals [V,3] (optional)."""
+        assert resolution == 176
+        self.engine = engine
+        mesh = U.load_ply_mesh(model) if isinstance(model, str) else model
+        v = np.ascontiguousarray(mesh["vertices"], np.float32)
+        f = np.ascontiguousarray(mesh["faces"], np.int32)
+        col = np.ascontiguousarray(np.asarray(mesh["colors"], np.float64) / 255.0, np.float32)
+        nrm = mesh.get("normals")
+        if nrm is None:
+            nrm = U.vertex_normals(v, f)
+        nrm = np.asarray(nrm, np.float64)
+        nrm = np.ascontiguousarray(nrm / np.linalg.norm(nrm, axis=1).reshape(-1, 1), np.float32)  # :126
+        self.mesh = dict(vertices=v, faces=f, colors01=col, normals=nrm)
+        h = C.c_void_p()
+        check(engine.lib.se3tn_mesh_create(engine._h, v.ctypes.data, nrm.ctypes.data, col.ctypes.data, len(v),
+                                           f.ctypes.data, len(f), C.byref(h)), "se3tn_mesh_create")
+        self._m = h
+        dev = "cuda:%d" % engine.device
+        self.rgb = torch.empty((176, 176, 3), dtype=torch.uint8, device=dev)
+        self.depth = torch.empty((176, 176), dtype=torch.int16, device=dev)  # uint16 bits
+
+    def __del__(self):
+        try:
+            if getattr(self, "_m", None):
+                self.engine.lib.se3tn_mesh_destroy(self._m)
+                self._m = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def gl_window(ob2cam, K, object_width):
+        """left, top, right, bottom as Tracker.render_window passes them to update_cam_mat
+        (predict.py:201-207): compute_bbox in the y-flipped GL image."""
+        bbox = U.compute_bbox(np.asarray(ob2cam, np.float64), K, object_width, scale=(1000, -1000, 1000))
+        return (int(np.min(bbox[:, 1])), int(np.min(bbox[:, 0])), int(np.max(bbox[:, 1])), int(np.max(bbox[:, 0])))
+
+    def render_device(self, ob2cam, K, gl_window, rgb=None, depth=None):
+        """Renders into device tensors (uint8 [176,176,3], uint16-as-int16 [176,176]); asynchronous."""
+        rgb = self.rgb if rgb is None else rgb
+        depth = self.depth if depth is None else depth
+        p = (C.c_double * 16)(*np.asarray(ob2cam, np.float64).reshape(16))
+        k = (C.c_double * 9)(*np.asarray(K, np.float64).reshape(9))
+        w = (C.c_int32 * 4)(*[int(x) for x in gl_window])
+        check(self.engine.lib.se3tn_render(self.engine._h, self._m, p, k, w, C.c_void_p(rgb.data_ptr()),
+                                           C.c_void_p(depth.data_ptr()), _stream_ptr()), "se3tn_render")
+        return rgb, depth
+
+    def render(self, ob2cam, K, gl_window):
+        """numpy (rgb uint8 [176,176,3], depth uint16 [176,176] mm), like VispyRenderer.render_image."""
+        rgb, depth = self.render_device(ob2cam, K, gl_window)
+        return rgb.cpu().numpy(), depth.cpu().numpy().view(np.uint16)

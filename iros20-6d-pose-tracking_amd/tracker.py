@@ -44,6 +44,13 @@ class Tracker:
         self.engine.set_normalizers(self.trans_normalizer, self.rot_normalizer)
         self.model = self.engine  # attribute name kept for callers that only check it exists
         self.renderer = renderer
+        if renderer is None and model_path is not None and model_path.endswith(".ply"):
+            # the reference builds a VispyRenderer from the .ply here (predict.py:180-182); ours is the
+            # HIP rasteriser -- only if the file has faces (the repo's bunny fixture has none)
+            from .renderer import HipRenderer
+            mesh = U.load_ply_mesh(model_path)
+            if len(mesh["faces"]) > 0:
+                self.renderer = HipRenderer(self.engine, mesh)
         self.prev_rgb = None
         self.prev_depth = None
         self.frame_cnt = 0
@@ -60,6 +67,9 @@ class Tracker:
         """predict.py:193-215.  Delegates to the injected renderer with the crop window."""
         if self.renderer is None:
             raise RuntimeError("Tracker.render_window: no renderer injected (rendering is outside the HIP hot path)")
+        from .renderer import HipRenderer
+        if isinstance(self.renderer, HipRenderer):
+            return self.renderer.render(ob2cam, self.K, HipRenderer.gl_window(ob2cam, self.K, self.object_width))
         bbox = U.compute_bbox(ob2cam, self.K, self.object_width, scale=(1000, 1000, 1000))
         return self.renderer.render(ob2cam, self.K, U.crop_window(bbox))
 
@@ -69,12 +79,17 @@ class Tracker:
         prev_pose 4x4 object-in-camera (metres).  Returns the 4x4 float64 pose estimate."""
         prev_pose = np.asarray(prev_pose, np.float64)
         bb = U.compute_bbox(prev_pose, self.K, self.object_width, scale=(1000, 1000, 1000))
-        rgbA, depthA = self.render_window(prev_pose)
         dev = self._dev
+        from .renderer import HipRenderer
+        if isinstance(self.renderer, HipRenderer):   # rendered A never leaves the device
+            rgbA_d, depA_d = self.renderer.render_device(
+                prev_pose, self.K, HipRenderer.gl_window(prev_pose, self.K, self.object_width))
+        else:
+            rgbA, depthA = self.render_window(prev_pose)
+            rgbA_d = torch.from_numpy(np.ascontiguousarray(rgbA)).to(dev, non_blocking=True)
+            depA_d = torch.from_numpy(np.ascontiguousarray(depthA).astype(np.uint16).view(np.int16)).to(dev, non_blocking=True)
         rgb_d = torch.from_numpy(np.ascontiguousarray(current_rgb)).to(dev, non_blocking=True)
         dep_d = torch.from_numpy(np.ascontiguousarray(current_depth).view(np.int16)).to(dev, non_blocking=True)
-        rgbA_d = torch.from_numpy(np.ascontiguousarray(rgbA)).to(dev, non_blocking=True)
-        depA_d = torch.from_numpy(np.ascontiguousarray(depthA).astype(np.uint16).view(np.int16)).to(dev, non_blocking=True)
         z_mm = float(prev_pose[2, 3]) * 1000
         res = self.image_size[0]
         n = int(samples)

@@ -68,6 +68,82 @@ def load_model_points(path):
         return rows[:, idx]
 
 
+def load_ply_mesh(path):
+    """Vertices, faces, vertex colours and normals of a .ply (ascii or binary_little_endian), the
+    fields VispyRenderer reads (vispy_renderer.py:113-127)."""
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"ply"
+        fmt, elems, cur = None, [], None
+        while True:
+            line = f.readline().strip().decode()
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                cur = dict(name=tok[1], count=int(tok[2]), props=[])
+                elems.append(cur)
+            elif tok[0] == "property":
+                cur["props"].append(tok[1:])
+            elif tok[0] == "end_header":
+                break
+        code = {"float": "f", "float32": "f", "double": "d", "float64": "d", "uchar": "B", "uint8": "B", "char": "b",
+                "int8": "b", "int": "i", "int32": "i", "uint": "I", "uint32": "I", "short": "h", "int16": "h",
+                "ushort": "H", "uint16": "H"}
+        data = {}
+        for el in elems:
+            names = [p_[-1] for p_ in el["props"]]
+            if el["name"] == "vertex":
+                if fmt == "ascii":
+                    arr = np.loadtxt(f, max_rows=el["count"], ndmin=2)
+                else:
+                    st = struct.Struct("<" + "".join(code[p_[0]] for p_ in el["props"]))
+                    raw = f.read(st.size * el["count"])
+                    arr = np.array([st.unpack_from(raw, i * st.size) for i in range(el["count"])], np.float64)
+                data["vertex"] = {n: arr[:, i] for i, n in enumerate(names)}
+            elif el["name"] == "face":
+                faces = []
+                if fmt == "ascii":
+                    for _ in range(el["count"]):
+                        t = f.readline().split()
+                        faces.append([int(x) for x in t[1:1 + int(t[0])]])
+                else:
+                    cnt_t, idx_t = code[el["props"][0][1]], code[el["props"][0][2]]
+                    for _ in range(el["count"]):
+                        (k,) = struct.unpack("<" + cnt_t, f.read(struct.calcsize(cnt_t)))
+                        faces.append(list(struct.unpack("<" + idx_t * k, f.read(struct.calcsize(idx_t) * k))))
+                data["face"] = faces
+            else:  # skip other elements (ascii only)
+                for _ in range(el["count"]):
+                    f.readline()
+    v = data["vertex"]
+    out = dict(vertices=np.stack([v["x"], v["y"], v["z"]], 1))
+    tri = [t for t in data.get("face", []) if len(t) == 3]
+    out["faces"] = np.asarray(tri, np.int32).reshape(-1, 3)
+    if "red" in v:
+        out["colors"] = np.stack([v["red"], v["green"], v["blue"]], 1)
+    else:
+        out["colors"] = np.full((len(out["vertices"]), 3), 255.0)
+    out["normals"] = np.stack([v["nx"], v["ny"], v["nz"]], 1) if "nx" in v else None
+    if out["normals"] is not None and not np.all(np.linalg.norm(out["normals"], axis=1) > 0):
+        out["normals"] = None
+    return out
+
+
+def vertex_normals(vertices, faces):
+    """Area-weighted vertex normals for meshes that store none."""
+    v = np.asarray(vertices, np.float64)
+    n = np.zeros_like(v)
+    fn = np.cross(v[faces[:, 1]] - v[faces[:, 0]], v[faces[:, 2]] - v[faces[:, 0]])
+    for k in range(3):
+        np.add.at(n, faces[:, k], fn)
+    ln = np.linalg.norm(n, axis=1)
+    n[ln > 0] /= ln[ln > 0, None]
+    n[ln == 0] = (0, 0, 1)
+    return n
+
+
 def voxel_down_sample(points, voxel_size=0.005):
     """open3d PointCloud.voxel_down_sample restated: grid origin = min_bound - voxel/2, one
     averaged point per occupied voxel (predict.py:133)."""

@@ -24,10 +24,18 @@ class StubRenderer:
         return self.rgb, self.depth
 
 
-def main(frames=300):
+def main(frames=300, faces_subdiv=None):
     mean, std = Fx.mean_std(0)
-    trk = se3.Tracker(Fx.DATASET_INFO, mean, std, {"state_dict": O.make_state_dict(0, head_gain=0.0005)},
-                      renderer=StubRenderer())
+    sd = {"state_dict": O.make_state_dict(0, head_gain=0.0005)}
+    if faces_subdiv is None:
+        trk = se3.Tracker(Fx.DATASET_INFO, mean, std, sd, renderer=StubRenderer())
+        rdesc = "stub renderer (pre-rendered arrays)"
+    else:  # full pipeline: HIP rasteriser on an icosphere with 20 * 4^subdiv faces (YCB scans: ~1e5 faces)
+        from oracle import raster_oracle as R
+        mesh = R.icosphere(faces_subdiv, 0.06, 0)
+        trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=150.0), mean, std, sd)
+        trk.renderer = se3.HipRenderer(trk.engine, mesh)
+        rdesc = "HIP rasteriser, %d faces, rendered A stays on the device" % len(mesh["faces"])
     rgb, depth = Fx.synthetic_frame(3)
     P = Fx.pose(3)
     for _ in range(20):
@@ -47,8 +55,9 @@ def main(frames=300):
     print(json.dumps({"on_track_ms_median": round(float(np.median(lat)), 4), "on_track_ms_p95": round(float(np.percentile(lat, 95)), 4),
                       "hz_median": round(1000.0 / float(np.median(lat)), 1), "device_infer_ms": round(tot_ms, 4),
                       "device_conv_ms": round(conv_ms, 4), "frames": frames,
-                      "note": "batch 1, 480x640 frame uploaded per call (pageable H2D), stub renderer, pose D2H sync per frame"}))
+                      "note": "batch 1, 480x640 frame uploaded per call (pageable H2D), %s, pose D2H sync per frame" % rdesc}))
 
 
 if __name__ == "__main__":
     main()
+    main(faces_subdiv=6)
