@@ -1,0 +1,89 @@
+/* Pure-C host of the hot path: proves the drop-in boundary is the C ABI of include/se3tracknet.h (no
+ * Python, no torch).  Reads a checkpoint dump + one batch of NCHW inputs + poses written by
+ * tests/test_c_host.py, runs se3tn_infer, writes trans | rot | poseB.
+ *
+ *   host_smoke <weights.bin> <inputs.bin> <outputs.bin>
+ *   weights.bin: int32 n_tensors, then per tensor: int32 key_len, key bytes, int32 ndim, int64 shape[ndim],
+ *                float32 data
+ *   inputs.bin : int32 n, float32 A[n,4,176,176], float32 B[n,4,176,176], float64 poseA[n,16]
+ *   outputs.bin: float32 trans[n,3], float32 rot[n,3], float64 poseB[n,16]
+ */
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "se3tracknet.h"
+
+#define CHECK(x)                                                                      \
+  do {                                                                                \
+    int rc_ = (x);                                                                    \
+    if (rc_ != 0) {                                                                   \
+      fprintf(stderr, "%s failed (rc=%d): %s\n", #x, rc_, se3tn_last_error());        \
+      return 1;                                                                       \
+    }                                                                                 \
+  } while (0)
+
+static int rd(void* dst, size_t bytes, FILE* f) { return fread(dst, 1, bytes, f) == bytes ? 0 : 1; }
+
+int main(int argc, char** argv) {
+  if (argc != 4) { fprintf(stderr, "usage: %s weights.bin inputs.bin outputs.bin\n", argv[0]); return 2; }
+  FILE* fw = fopen(argv[1], "rb");
+  FILE* fi = fopen(argv[2], "rb");
+  if (!fw || !fi) { perror("open"); return 2; }
+  int32_t n;
+  if (rd(&n, 4, fi)) return 2;
+
+  se3tn_ctx* ctx = NULL;
+  CHECK(se3tn_create(0, n, &ctx));
+  int32_t nt;
+  if (rd(&nt, 4, fw)) return 2;
+  for (int t = 0; t < nt; ++t) {
+    int32_t klen, ndim;
+    char key[256];
+    int64_t shape[4];
+    if (rd(&klen, 4, fw) || klen > 255 || rd(key, (size_t)klen, fw)) return 2;
+    key[klen] = 0;
+    if (rd(&ndim, 4, fw) || ndim > 4 || rd(shape, 8 * (size_t)ndim, fw)) return 2;
+    size_t count = 1;
+    for (int d = 0; d < ndim; ++d) count *= (size_t)shape[d];
+    float* data = (float*)malloc(count * 4);
+    if (rd(data, count * 4, fw)) return 2;
+    CHECK(se3tn_set_tensor(ctx, key, data, shape, ndim));
+    free(data);
+  }
+  CHECK(se3tn_pack_weights(ctx));
+  CHECK(se3tn_upload_weights(ctx, NULL));
+  CHECK(se3tn_set_normalizers(ctx, 0.03, 5 * 3.14159265358979323846 / 180));
+
+  const size_t img = (size_t)n * 4 * 176 * 176 * 4;
+  float *hA = (float*)malloc(img), *hB = (float*)malloc(img);
+  double* hP = (double*)malloc((size_t)n * 16 * 8);
+  if (rd(hA, img, fi) || rd(hB, img, fi) || rd(hP, (size_t)n * 16 * 8, fi)) return 2;
+  float *dA, *dB, *dT, *dR;
+  double *dPA, *dPB;
+  if (hipMalloc((void**)&dA, img) || hipMalloc((void**)&dB, img) || hipMalloc((void**)&dT, n * 12) ||
+      hipMalloc((void**)&dR, n * 12) || hipMalloc((void**)&dPA, n * 128) || hipMalloc((void**)&dPB, n * 128)) return 3;
+  hipMemcpy(dA, hA, img, hipMemcpyHostToDevice);
+  hipMemcpy(dB, hB, img, hipMemcpyHostToDevice);
+  hipMemcpy(dPA, hP, (size_t)n * 128, hipMemcpyHostToDevice);
+  CHECK(se3tn_infer(ctx, dA, dB, n, SE3TN_NCHW, dT, dR, dPA, dPB, NULL));
+  if (hipDeviceSynchronize() != hipSuccess) return 3;
+
+  float* oT = (float*)malloc((size_t)n * 12);
+  float* oR = (float*)malloc((size_t)n * 12);
+  double* oP = (double*)malloc((size_t)n * 128);
+  hipMemcpy(oT, dT, (size_t)n * 12, hipMemcpyDeviceToHost);
+  hipMemcpy(oR, dR, (size_t)n * 12, hipMemcpyDeviceToHost);
+  hipMemcpy(oP, dPB, (size_t)n * 128, hipMemcpyDeviceToHost);
+  FILE* fo = fopen(argv[3], "wb");
+  fwrite(oT, 1, (size_t)n * 12, fo); fwrite(oR, 1, (size_t)n * 12, fo); fwrite(oP, 1, (size_t)n * 128, fo);
+  fclose(fo);
+  /* host-side entry points from C as well */
+  int32_t vu[8];
+  const double K[9] = {1066.778, 0, 312.9869, 0, 1067.487, 241.3109, 0, 0, 1};
+  CHECK(se3tn_compute_bbox(hP, K, 250.0, vu));
+  printf("ok n=%d version=\"%s\" bbox0=(%d,%d)\n", n, se3tn_version(), vu[0], vu[1]);
+  se3tn_destroy(ctx);
+  return 0;
+}

@@ -1,0 +1,64 @@
+"""The boundary is a C ABI: a pure-C host program (tests/c_abi/host_smoke.c, gcc + the shared library +
+the HIP runtime, no Python in the process) loads a checkpoint dump, runs se3tn_infer and must produce
+what the oracle computes."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import fixtures as Fx
+from oracle import se3_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "iros20-6d-pose-tracking_amd")
+
+
+def _build(tmp):
+    exe = os.path.join(tmp, "host_smoke")
+    cmd = ["gcc", "-O1", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+           os.path.join(ROOT, "tests", "c_abi", "host_smoke.c"), "-o", exe, "-L" + LIBDIR, "-lse3tracknet",
+           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_c_host_compiles_and_links(tmp_path):
+    """CPU: header is valid C, every used symbol resolves against the built library."""
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    assert os.path.isfile(_build(str(tmp_path)))
+
+
+@pytest.mark.gpu
+def test_c_host_matches_oracle(tmp_path):
+    exe = _build(str(tmp_path))
+    sd = O.make_state_dict(0)
+    n = 2
+    A, B = Fx.net_inputs(31, n)
+    poses = np.stack([Fx.pose(80 + i, (0.01, 0.02, 0.7)) for i in range(n)])
+    with open(tmp_path / "w.bin", "wb") as f:
+        tens = [(k, v) for k, v in sd.items() if v.dtype.is_floating_point]
+        f.write(struct.pack("<i", len(tens)))
+        for k, v in tens:
+            kb = k.encode()
+            f.write(struct.pack("<i", len(kb))); f.write(kb)
+            f.write(struct.pack("<i", v.dim())); f.write(struct.pack("<%dq" % v.dim(), *v.shape))
+            f.write(v.numpy().astype("<f4").tobytes())
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<i", n)); f.write(A.numpy().tobytes()); f.write(B.numpy().tobytes()); f.write(poses.tobytes())
+    out = subprocess.run([exe, str(tmp_path / "w.bin"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.startswith("ok n=2")
+    raw = open(tmp_path / "out.bin", "rb").read()
+    trans = np.frombuffer(raw[:n * 12], np.float32).reshape(n, 3)
+    rot = np.frombuffer(raw[n * 12:n * 24], np.float32).reshape(n, 3)
+    poseB = np.frombuffer(raw[n * 24:], np.float64).reshape(n, 4, 4)
+    ref = O.forward(sd, A, B)
+    assert np.abs(trans - ref["trans"].numpy()).max() < 1e-4 and np.abs(rot - ref["rot"].numpy()).max() < 1e-4
+    for i in range(n):
+        want = O.process_predict(poses[i], trans[i], rot[i])
+        assert np.abs(poseB[i] - want).max() < 1e-12
