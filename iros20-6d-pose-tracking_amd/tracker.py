@@ -108,3 +108,40 @@ class Tracker:
         self.prev_depth = current_depth
         self.frame_cnt += 1
         return poseB[0]
+
+    def on_track_batch(self, prev_poses, rgbs, depths):
+        """Extension: n independent (pose, frame) pairs of the SAME object in one engine call -- several
+        sequences / cameras / hypotheses (frames of one track are serial, so this is where batch > 1
+        comes from).  Same arithmetic per pair as on_track; returns [n,4,4] float64."""
+        from .renderer import HipRenderer
+        n = len(prev_poses)
+        if n > self.engine.max_batch:
+            raise ValueError("on_track_batch: %d pairs > max_samples=%d given to Tracker()" % (n, self.engine.max_batch))
+        dev = self._dev
+        cropsA, cropsB, keep = [], [], []
+        poses = np.stack([np.asarray(p, np.float64) for p in prev_poses])
+        for i in range(n):
+            bb = U.compute_bbox(poses[i], self.K, self.object_width, scale=(1000, 1000, 1000))
+            if isinstance(self.renderer, HipRenderer):
+                rgbA_d = torch.empty((176, 176, 3), dtype=torch.uint8, device=dev)
+                depA_d = torch.empty((176, 176), dtype=torch.int16, device=dev)
+                self.renderer.render_device(poses[i], self.K, HipRenderer.gl_window(poses[i], self.K, self.object_width),
+                                            rgbA_d, depA_d)
+            else:
+                rgbA, depthA = self.render_window(poses[i])
+                rgbA_d = torch.from_numpy(np.ascontiguousarray(rgbA)).to(dev)
+                depA_d = torch.from_numpy(np.ascontiguousarray(depthA).astype(np.uint16).view(np.int16)).to(dev)
+            rgb_d = torch.from_numpy(np.ascontiguousarray(rgbs[i])).to(dev, non_blocking=True)
+            dep_d = torch.from_numpy(np.ascontiguousarray(depths[i]).view(np.int16)).to(dev, non_blocking=True)
+            keep += [rgbA_d, depA_d, rgb_d, dep_d]
+            z_mm = float(poses[i, 2, 3]) * 1000
+            cropsA.append(dict(rgb=rgbA_d, depth=depA_d, window=(0, 0, 176, 176), z_offset_mm=z_mm, stats=0))
+            cropsB.append(dict(rgb=rgb_d, depth=dep_d, window=U.crop_window(bb), z_offset_mm=z_mm, stats=1))
+        self.engine.preprocess(cropsA, self.engine.input_buffer_ptr(0))
+        self.engine.preprocess(cropsB, self.engine.input_buffer_ptr(1))
+        self._poseA[:n].copy_(torch.from_numpy(poses.reshape(n, 16)), non_blocking=True)
+        self.engine.infer(self.engine.input_buffer_ptr(0), self.engine.input_buffer_ptr(1), n, NHWC,
+                          self._trans, self._rot, self._poseA, self._poseB)
+        out = self._poseB[:n].cpu().numpy().reshape(n, 4, 4)
+        self.frame_cnt += 1
+        return out

@@ -183,3 +183,17 @@ def test_tracker_samples_gt_1_and_bind_blob_path(se3):
     eng2.infer(A.cuda(), B.cuda(), 1, se3.NCHW, t_a, None)
     trk.engine.infer(A.cuda(), B.cuda(), 1, se3.NCHW, t_b, None)
     assert (t_a == t_b).all()
+
+
+def test_on_track_batch_equals_sequential(se3):
+    sd = O.make_state_dict(0, head_gain=0.002)
+    mean, std = Fx.mean_std(0)
+    trk = se3.Tracker(Fx.DATASET_INFO, mean, std, {"state_dict": sd}, renderer=_Render(), max_samples=8)
+    frames = [Fx.synthetic_frame(70 + i) for i in range(5)]
+    poses = [Fx.pose(3 + i, (0.02 * i - 0.04, 0.01, 0.7 + 0.05 * i)) for i in range(5)]
+    seq = np.stack([trk.on_track(poses[i], *frames[i]) for i in range(5)])
+    bat = trk.on_track_batch(poses, [f[0] for f in frames], [f[1] for f in frames])
+    assert bat.shape == (5, 4, 4)
+    assert np.abs(bat - seq).max() < 1e-9   # same kernels (small-batch path), fixed-order reductions
+    with pytest.raises(ValueError):
+        trk.on_track_batch(poses * 2, [f[0] for f in frames] * 2, [f[1] for f in frames] * 2)
