@@ -116,6 +116,11 @@ float* se3tn_input_buffer(se3tn_ctx* ctx, int which);
  *   poseB    device float64 [n,16]: t_B = trans*tn + t_A,  R_B = Rodrigues(rot*rn) . R_A     */
 int se3tn_infer(se3tn_ctx* ctx, const float* A, const float* B, int n, int layout, float* trans,
                 float* rot, const double* poseA, double* poseB, void* stream);
+/* hipGraph replay of se3tn_infer (off by default).  When on, the second se3tn_infer with an argument
+ * set (pointers, n, layout, modes) captures its launches on `stream` (which must not be the null stream)
+ * and later calls replay the graph: for the launch-bound batch-1 tracking step.  The input / output /
+ * pose buffers must therefore be persistent device buffers whose CONTENTS change between calls. */
+int se3tn_enable_graphs(se3tn_ctx* ctx, int on);
 /* output['feature'] (se3_tracknet.py:96): device float32 [n,256,22,22] NCHW, valid after infer */
 int se3tn_get_feature(se3tn_ctx* ctx, int n, float* feature_nchw, void* stream);
 /* pre-tanh FC outputs of the last se3tn_infer: device float32 [max_batch,6] (trans, rot) */

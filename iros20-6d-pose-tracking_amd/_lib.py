@@ -47,6 +47,7 @@ _SIGS = {
     "se3tn_input_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
     "se3tn_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "se3tn_enable_graphs": (C.c_int, [C.c_void_p, C.c_int]),
     "se3tn_get_feature": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "se3tn_logits": (C.c_void_p, [C.c_void_p]),
     "se3tn_mesh_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

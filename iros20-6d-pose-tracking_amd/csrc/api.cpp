@@ -29,6 +29,20 @@ static int hipfail(hipError_t e, const char* what) {
 
 enum { MAX_LAUNCHES = 24, MAX_SLOTS = 64 };
 
+// one captured se3tn_infer: every argument that is baked into the kernel launches
+struct GraphKey {
+  const void *A, *B, *trans, *rot, *poseA, *poseB, *blob;
+  int n, layout, prec;
+  double tn, rn;
+  bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
+};
+struct GraphEntry {
+  GraphKey key;
+  hipGraphExec_t exec = nullptr;  // null: seen once (run eagerly, which also sets the kernels' LDS attributes)
+  bool fast = false;
+  const float* head_final = nullptr;
+};
+
 struct se3tn_ctx {
   int device = -1, max_batch = 0;
   TensorMap tensors;
@@ -54,6 +68,8 @@ struct se3tn_ctx {
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
   int* overflow = nullptr;                      // device flag: a split-row store left the f16 range
   unsigned long long* zbuf = nullptr;           // rasteriser z-buffer keys [176*176]
+  bool use_graphs = false;                      // se3tn_enable_graphs
+  std::vector<GraphEntry> graphs;
   double mean[8], stdv[8];
   bool have_norm = false;
   double tn = 0.03, rn = 5.0 * 3.14159265358979323846 / 180.0;
@@ -140,6 +156,8 @@ void se3tn_destroy(se3tn_ctx* c) {
                      c->head_t, c->head_f, c->logits, c->part, c->blob_owned};
     for (float* b : bufs)
       if (b) (void)hipFree(b);
+    for (auto& g : c->graphs)
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (c->overflow) (void)hipFree(c->overflow);
     if (c->zbuf) (void)hipFree(c->zbuf);
     for (int s = 0; s < c->slots; ++s)
@@ -267,8 +285,65 @@ static int prof_mark(se3tn_ctx* c, hipStream_t st, const char* name, bool is_con
   return (int)hipEventRecord(c->ev[c->n_launch], st);
 }
 
+static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int layout, float* trans, float* rot,
+                        const double* poseA, double* poseB, void* stream);
+
+int se3tn_enable_graphs(se3tn_ctx* c, int on) {
+  if (!c || c->device < 0) return fail(SE3TN_E_ARG, "se3tn_enable_graphs: no device context");
+  c->use_graphs = on != 0;
+  return SE3TN_OK;
+}
+
+// With graphs enabled, the ~25 dependent launches of one se3tn_infer are captured once per argument
+// set (second call with identical arguments; the first runs eagerly) and replayed with one
+// hipGraphLaunch afterwards: the batch-1 tracking step is launch-bound (kernels of 10-30 us).
 int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout, float* trans, float* rot,
                 const double* poseA, double* poseB, void* stream) {
+  if (!c || !c->use_graphs || c->prof || stream == nullptr)  // the null stream cannot be captured
+    return infer_launch(c, A, B, n, layout, trans, rot, poseA, poseB, stream);
+  GraphKey key;
+  std::memset(&key, 0, sizeof(key));
+  key.A = A; key.B = B; key.trans = trans; key.rot = rot; key.poseA = poseA; key.poseB = poseB; key.blob = c->blob;
+  key.n = n; key.layout = layout; key.prec = c->prec; key.tn = c->tn; key.rn = c->rn;
+  hipStream_t st = (hipStream_t)stream;
+  for (auto& g : c->graphs) {
+    if (!(g.key == key)) continue;
+    if (g.exec) {
+      const int want_split = c->prec == SE3TN_PREC_F16X3 ? 1 : 0;
+      if ((A == c->inA && c->in_split[0] != want_split) || (B == c->inB && c->in_split[1] != want_split))
+        return fail(SE3TN_E_STATE, "se3tn_infer: the input buffers were filled under a different precision mode");
+      HIPCHK(hipGraphLaunch(g.exec, st));
+      c->last_fast = g.fast;
+      c->head_final = g.head_final;
+      return SE3TN_OK;
+    }
+    // second sighting: capture
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = infer_launch(c, A, B, n, layout, trans, rot, poseA, poseB, stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc != SE3TN_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return hipfail(e, "hipStreamEndCapture");
+    const hipError_t e2 = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e2 != hipSuccess) { g.exec = nullptr; return hipfail(e2, "hipGraphInstantiate"); }
+    g.fast = c->last_fast;
+    g.head_final = c->head_final;
+    HIPCHK(hipGraphLaunch(g.exec, st));
+    return SE3TN_OK;
+  }
+  if (c->graphs.size() >= 16) {  // bounded cache: drop the oldest entry
+    if (c->graphs.front().exec) (void)hipGraphExecDestroy(c->graphs.front().exec);
+    c->graphs.erase(c->graphs.begin());
+  }
+  GraphEntry ge;
+  ge.key = key;
+  c->graphs.push_back(ge);
+  return infer_launch(c, A, B, n, layout, trans, rot, poseA, poseB, stream);
+}
+
+static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int layout, float* trans, float* rot,
+                        const double* poseA, double* poseB, void* stream) {
   if (!c || c->device < 0 || !A || !B) return fail(SE3TN_E_ARG, "se3tn_infer: bad argument");
   if (n < 1 || n > c->max_batch) return fail(SE3TN_E_ARG, "se3tn_infer: n outside [1, max_batch]");
   if (!c->blob) return fail(SE3TN_E_STATE, "se3tn_infer: weights not uploaded/bound");

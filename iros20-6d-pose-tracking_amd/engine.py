@@ -82,6 +82,10 @@ class Engine:
         s = (C.c_double * 8)(*[float(x) for x in np.asarray(std).reshape(8)])
         check(self.lib.se3tn_set_normalization(self._h, m, s), "se3tn_set_normalization")
 
+    def enable_graphs(self, on=True):
+        """hipGraph replay of repeated se3tn_infer calls (needs a non-default stream)."""
+        check(self.lib.se3tn_enable_graphs(self._h, 1 if on else 0), "se3tn_enable_graphs")
+
     def set_precision(self, mode):
         """_lib.PREC_F32 (default, exact) or _lib.PREC_F16X3 (split-f16 MFMA for the deep layers, n >= 32)."""
         check(self.lib.se3tn_set_precision(self._h, int(mode)), "se3tn_set_precision")

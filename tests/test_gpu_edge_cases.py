@@ -197,3 +197,19 @@ def test_on_track_batch_equals_sequential(se3):
     assert np.abs(bat - seq).max() < 1e-9   # same kernels (small-batch path), fixed-order reductions
     with pytest.raises(ValueError):
         trk.on_track_batch(poses * 2, [f[0] for f in frames] * 2, [f[1] for f in frames] * 2)
+
+
+def test_hipgraph_replay_matches_eager(se3):
+    """se3tn_enable_graphs: the captured se3tn_infer replays bit-identically, tracks argument changes
+    (new pointers -> new capture) and content changes (same buffers, new data)."""
+    sd = O.make_state_dict(0, head_gain=0.002)
+    mean, std = Fx.mean_std(0)
+    eager = se3.Tracker(Fx.DATASET_INFO, mean, std, {"state_dict": sd}, renderer=_Render(), use_graphs=False)
+    graph = se3.Tracker(Fx.DATASET_INFO, mean, std, {"state_dict": sd}, renderer=_Render(), use_graphs=True)
+    Pe = Pg = Fx.pose(3)
+    for f in range(5):  # call 1 eager, call 2 captures, calls 3.. replay
+        rgb, depth = Fx.synthetic_frame(90 + f)
+        Pe = eager.on_track(Pe, rgb, depth)
+        Pg = graph.on_track(Pg, rgb, depth)
+        assert (Pe == Pg).all(), f
+    assert any(g for g in [graph.engine]) and graph._stream is not None
