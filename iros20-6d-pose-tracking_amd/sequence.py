@@ -68,3 +68,62 @@ def predict_sequence_ycb(tracker, seq_dir, class_id, out_dir, start_frame=0, rei
             except IndexError:  # no frame below 0.1 m: the reference's VOCap raises
                 res[name] = 0.0
     return res
+
+
+def get_results_ycb(tracker, ycb_dir, class_id, out_dir, seq_ids=None, max_frames=None):
+    """The loop of predict.py:299-443 `getResultsYcb` (GT initialisation, no re-init, no video): every
+    sequence under <ycb_dir>/data_organized/ that has pose_gt/<class_id>/ is tracked from its first
+    frame and written as <out_dir>/seq<ID>/%07d.txt -- the layout eval_one_class / the reference's
+    eval_ycb.py:95-96 parse (file index = frame id - 1).  Returns {seq_id: n_poses}."""
+    root = os.path.join(ycb_dir, "data_organized")
+    done = {}
+    for seq_dir in sorted(glob.glob(os.path.join(root, "*"))):
+        if not os.path.isdir(os.path.join(seq_dir, "pose_gt", str(class_id))):
+            continue
+        seq_id = int(os.path.basename(seq_dir))
+        if seq_ids is not None and seq_id not in seq_ids:
+            continue
+        rgb_files = sorted(glob.glob(os.path.join(seq_dir, "color", "*")))
+        depth_files = sorted(glob.glob(os.path.join(seq_dir, "depth_filled", "*")))
+        gt_files = sorted(glob.glob(os.path.join(seq_dir, "pose_gt", str(class_id), "*")))
+        n = len(rgb_files) if max_frames is None else min(len(rgb_files), max_frames)
+        prev_pose = np.loadtxt(gt_files[0])
+        pred = [prev_pose]
+        for i in range(1, n):
+            cur = tracker.on_track(prev_pose, read_rgb(rgb_files[i]), read_depth_mm(depth_files[i]),
+                                   gt_A_in_cam=None, gt_B_in_cam=np.loadtxt(gt_files[i]))
+            prev_pose = cur.copy()
+            pred.append(cur)
+        sdir = os.path.join(out_dir, "seq%d" % seq_id)
+        os.makedirs(sdir, exist_ok=True)
+        for i, p in enumerate(pred):
+            np.savetxt(os.path.join(sdir, "%07d.txt" % i), p)
+        done[seq_id] = len(pred)
+    return done
+
+
+def eval_one_class(res_dir, ycb_dir, class_id):
+    """eval_ycb.py:67-119: ADD / ADD-S AUC (x100) of the keyframe poses found under res_dir/seq*/,
+    against <ycb_dir>/data_organized/%04d/pose_gt/<class_id>/%06d.txt, with the class's
+    CADmodels/*/points.xyz as the model and YCB_Video_toolbox/keyframe.txt as the frame filter."""
+    pose_files = sorted(glob.glob(os.path.join(res_dir, "**", "*.txt"), recursive=True))
+    assert len(pose_files) > 0, "no pose files under %s" % res_dir
+    model_files = sorted(glob.glob(os.path.join(ycb_dir, "CADmodels", "**", "points.xyz"), recursive=True))
+    model_pts = np.loadtxt(model_files[class_id - 1]).reshape(-1, 3)
+    with open(os.path.join(ycb_dir, "YCB_Video_toolbox", "keyframe.txt")) as ff:
+        keyframes = set(line.rstrip() for line in ff)
+    adi_errs, add_errs = [], []
+    for pose_file in pose_files:
+        rel = os.path.relpath(pose_file, res_dir).split(os.sep)
+        seq_id = int(rel[0].replace("seq", ""))
+        frame_id = int(os.path.basename(pose_file).split(".")[0]) + 1
+        if "%04d/%06d" % (seq_id, frame_id) not in keyframes:
+            continue
+        pred = np.loadtxt(pose_file)
+        gt = np.loadtxt(os.path.join(ycb_dir, "data_organized", "%04d" % seq_id, "pose_gt", str(class_id), "%06d.txt" % frame_id))
+        adi_errs.append(metrics.adi(pred, gt, model_pts))
+        add_errs.append(metrics.add(pred, gt, model_pts))
+    assert len(adi_errs) > 0, "no keyframe among the result files"
+    adi_errs = np.sort(np.array(adi_errs)); add_errs = np.sort(np.array(add_errs))
+    return {"add_auc": metrics.VOCap(add_errs) * 100, "adi_auc": metrics.VOCap(adi_errs) * 100,
+            "adi_errs": adi_errs, "add_errs": add_errs, "n": len(adi_errs)}

@@ -93,3 +93,35 @@ def test_sequence_driver_on_synthetic_ycb_layout(se3, tmp_path):
     want, _ = O.on_track(sd, P, rgb1, depth1, *Fx.synthetic_render(11, P[2, 3]), Fx.K_YCB, trk.object_width, mean, std)
     assert np.abs(res["poses"][1] - want).max() < 1e-5
     assert 0.0 <= res["adi_auc"] <= 100.0 and len(res["adi_errs"]) == n
+
+
+@pytest.mark.gpu
+def test_get_results_and_eval_one_class_file_formats(se3, tmp_path):
+    """getResultsYcb layout in, eval_ycb layout out: seq<ID>/%07d.txt with file index = frame id - 1,
+    keyframe filter, CADmodels/*/points.xyz -- on a synthetic data_organized tree."""
+    ycb = tmp_path / "ycb"
+    P = Fx.pose(3)
+    for seq, nfr in ((48, 4), (50, 3)):
+        for d in ("color", "depth_filled", "pose_gt/2"):
+            os.makedirs(ycb / "data_organized" / ("%04d" % seq) / d)
+        for i in range(nfr):
+            rgb, depth = Fx.synthetic_frame(100 + seq + i)
+            Image.fromarray(rgb).save(ycb / "data_organized" / ("%04d" % seq) / "color" / ("%06d.png" % (i + 1)))
+            Image.fromarray(depth).save(ycb / "data_organized" / ("%04d" % seq) / "depth_filled" / ("%06d.png" % (i + 1)))
+            np.savetxt(ycb / "data_organized" / ("%04d" % seq) / "pose_gt/2" / ("%06d.txt" % (i + 1)), P)
+    os.makedirs(ycb / "data_organized" / "0049" / "color")            # a sequence without this class
+    for c in ("001_a", "002_b"):
+        os.makedirs(ycb / "CADmodels" / c)
+        np.savetxt(ycb / "CADmodels" / c / "points.xyz", np.random.default_rng(1).uniform(-0.04, 0.04, (200, 3)))
+    os.makedirs(ycb / "YCB_Video_toolbox")
+    (ycb / "YCB_Video_toolbox" / "keyframe.txt").write_text("0048/000001\n0048/000003\n0050/000002\n0051/000001\n")
+    sd = O.make_state_dict(0, head_gain=0.0005)
+    mean, std = Fx.mean_std(0)
+    trk = se3.Tracker(Fx.DATASET_INFO, mean, std, {"state_dict": sd}, renderer=_Render())
+    out = str(tmp_path / "res") + "/"
+    done = se3.sequence.get_results_ycb(trk, str(ycb), 2, out)
+    assert done == {48: 4, 50: 3}
+    assert sorted(os.listdir(out)) == ["seq48", "seq50"] and sorted(os.listdir(out + "seq48"))[0] == "0000000.txt"
+    assert np.allclose(np.loadtxt(out + "seq48/0000000.txt"), P)     # GT initialisation
+    res = se3.sequence.eval_one_class(out, str(ycb), 2)
+    assert res["n"] == 3 and 0 <= res["adi_auc"] <= 100 and res["adi_errs"][0] == 0.0   # frame 1 == GT
