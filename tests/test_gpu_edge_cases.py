@@ -213,3 +213,25 @@ def test_hipgraph_replay_matches_eager(se3):
         Pg = graph.on_track(Pg, rgb, depth)
         assert (Pe == Pg).all(), f
     assert any(g for g in [graph.engine]) and graph._stream is not None
+
+
+def test_large_batch_192_matches_single_pairs(se3):
+    """Maximum-size style check: a 192-pair call (3x BASELINE's batch; offsets beyond 2^31 bytes in the
+    stem buffer) agrees pair-by-pair with single-pair calls, in both arithmetic modes."""
+    sd = O.make_state_dict(0)
+    m = se3.Se3TrackNet(176, max_batch=192)
+    m.load_state_dict(sd); m.cuda(0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.randn((192, 4, 176, 176), generator=g, device="cuda")
+    B = torch.randn((192, 4, 176, 176), generator=g, device="cuda")
+    big = m(A, B, return_feature=False)
+    t, r = big["trans"].clone(), big["rot"].clone()
+    for i in (0, 97, 191):
+        one = m(A[i:i + 1], B[i:i + 1], return_feature=False)
+        assert float((one["trans"][0] - t[i]).abs().max()) < 5e-6 and float((one["rot"][0] - r[i]).abs().max()) < 5e-6
+    ref = O.forward(sd, A[[191]].cpu(), B[[191]].cpu())
+    assert float((t[191].cpu() - ref["trans"][0]).abs().max()) < 1e-4
+    m.engine.set_precision(se3._lib.PREC_F16X3)
+    fast = m(A, B, return_feature=False)
+    assert not m.engine.overflow()
+    assert float((fast["trans"] - t).abs().max()) < 2e-5 and float((fast["rot"] - r).abs().max()) < 2e-5
