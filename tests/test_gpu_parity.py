@@ -266,3 +266,46 @@ def test_f16x3_mode_parity_and_overflow_guard(se3, model0):
         assert not eng.overflow()  # reading clears the flag
     finally:
         eng.set_precision(se3._lib.PREC_F32)
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_f16x3_numerics_under_awkward_scales(se3, seed):
+    """The split-f16 path on weights / activations that stress its range handling: per-layer weight
+    magnitudes from 1e-3 to 30 (the host scales every cout row by an exact power of two before
+    splitting), a dead cout row (all-zero weights), heavy-tailed inputs.  Against the CPU oracle on 2
+    pairs and against the float32 kernels on all 32."""
+    g = torch.Generator().manual_seed(seed)
+    sd = O.make_state_dict(seed, head_gain=1.0)
+    facs = {}
+    for k in list(sd.keys()):
+        if k.endswith("weight") and sd[k].dim() == 4:
+            f = float(10 ** (torch.rand(1, generator=g) * 4.5 - 3.0))   # 1e-3 .. 30
+            sd[k] = sd[k] * f
+            facs[k] = f
+            # keep activations O(1): the BN that follows absorbs the scale through its running statistics
+            bn = k.replace(".0.weight", ".1.weight").replace("conv1.weight", "bn1.weight").replace("conv2.weight", "bn2.weight")
+            sd[k.replace("weight", "bias")] = sd[k.replace("weight", "bias")] * f
+            rm = bn.replace("weight", "running_mean"); rv = bn.replace("weight", "running_var")
+            sd[rm] = sd[rm] * f; sd[rv] = sd[rv] * f * f
+    sd["trans_conv2.conv1.weight"][7] = 0.0          # a dead output channel
+    sd["trans_out.0.weight"] *= 0.02; sd["rot_out.0.weight"] *= 0.02
+    n = 32
+    A = torch.randn((n, 4, 176, 176), generator=g) * (1.0 + 20.0 * (torch.rand((n, 4, 176, 176), generator=g) > 0.999))
+    B = torch.randn((n, 4, 176, 176), generator=g) * 3.0
+    m = se3.Se3TrackNet(176, max_batch=n)
+    m.load_state_dict(sd); m.cuda(0)
+    eng = m.engine
+    m(A.cuda(), B.cuda(), return_feature=False)
+    l32 = eng.logits(n).clone()
+    eng.set_precision(se3._lib.PREC_F16X3)
+    m(A.cuda(), B.cuda(), return_feature=False)
+    l16 = eng.logits(n).clone()
+    assert not eng.overflow()
+    ref = O.forward(sd, A[:2], B[:2])
+    want = torch.cat([ref["trans_logit"], ref["rot_logit"]], 1)
+    scale = float(want.abs().max()) + 1.0
+    e32 = float((l32[:2].cpu() - want).abs().max()) / scale
+    e16 = float((l16[:2].cpu() - want).abs().max()) / scale
+    d = float((l16 - l32).abs().max()) / scale
+    print("seed %d: rel err f32 %.2e  f16x3 %.2e  |f16x3 - f32| %.2e (logit scale %.2f)" % (seed, e32, e16, d, scale))
+    assert e32 < 2e-5 and e16 < 2e-5 and d < 2e-5
