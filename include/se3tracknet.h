@@ -69,7 +69,7 @@ int se3tn_bind_weights(se3tn_ctx* ctx, const void* device_blob, size_t bytes);
 /* ---- per-dataset constants --------------------------------------------------------------- */
 /* mean.npy / std.npy: float64[8] = A(R,G,B,D), B(R,G,B,D) (predict.py:657-658). */
 int se3tn_set_normalization(se3tn_ctx* ctx, const double mean[8], const double std[8]);
-/* Arithmetic of the 256/512-channel convolutions (72 % of the FLOPs) when n >= 32:
+/* Arithmetic of the convolutions:
  *   SE3TN_PREC_F32   (default) exact float32 MFMA everywhere;
  *   SE3TN_PREC_F16X3 operands split into f16 hi + f16 lo (22 significant bits), products formed as
  *                    hi*hi + hi*lo + lo*hi on the f16 matrix cores with float32 accumulation:

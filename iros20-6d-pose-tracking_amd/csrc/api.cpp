@@ -382,8 +382,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
   else
     HIPCHK(launch_stem(A, B, W + L.stem_w, W + L.stem_b, nullptr, c->stem, n, st));
   HIPCHK((hipError_t)prof_mark(c, st, "stem7x7_mfma", false));
-  // f16x3 mode applies to the throughput regime only (the small-batch split-K path stays float32)
-  const bool fast = c->prec == SE3TN_PREC_F16X3 && n >= 32;
+  const bool fast = c->prec == SE3TN_PREC_F16X3;  // both the big-tile and the split-K kernels
   c->last_fast = fast;
   HIPCHK(launch_maxpool(c->stem, c->pool, n, fast ? 1 : 0, st));
   HIPCHK((hipError_t)prof_mark(c, st, "maxpool3x3s2", false));

@@ -481,11 +481,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gather_s2_kernel(const ConvArg
 // small-batch (latency) path: split-K.  At batch 1 the big-tile kernels above would occupy 8-64 of
 // the 256 CUs (M = 121..1936 rows), so the K dimension is cut into `slices` runs of 32-channel chunks
 // handled by different workgroups (128 px x {128|64} cout, 4 waves, per-tap gather on the
-// zero-bordered input, stride 1 or 2).  Each workgroup stores its raw partial accumulators to
+// zero-bordered input, stride 1 or 2, either arithmetic mode).  Each workgroup stores its raw partial accumulators to
 // part[slice][group][M][cout]; conv_reduce_kernel sums the slices in a FIXED order (deterministic,
 // no atomics) and applies the bias / residual / activation epilogue into the padded output.
 // =================================================================================================
-template <int CIN, int STRIDE, int CT>
+template <int CIN, int STRIDE, int CT, int MM>
 __global__ __launch_bounds__(256, 2) void conv3x3_splitk_kernel(const ConvArgs a) {
   constexpr int BM = 128, BN = 64 * CT, PT = 2;
   constexpr int NCH = CIN / 32;
@@ -560,14 +560,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_splitk_kernel(const ConvArgs a
     if (kt + 1 < KT) ISSUE_TILE(ch, tap, buf ^ 1)
     const float* pP = smem + buf * BUF + (wm * PT * 32 + l31) * 32;
     const float* pW = smem + buf * BUF + (BM + wn * CT * 32 + l31) * 32;
-    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo0),
-                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo0))
-    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo1),
-                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo1))
-    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo2),
-                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo2))
-    SE3TN_MMA_GROUP(PT, CT, *reinterpret_cast<const float4*>(pP + i * 1024 + fo3),
-                    *reinterpret_cast<const float4*>(pW + j * 1024 + fo3))
+#define FOG(G) ((G) == 0 ? fo0 : (G) == 1 ? fo1 : (G) == 2 ? fo2 : fo3)
+#define PXF(G) *reinterpret_cast<const float4*>(pP + i * 1024 + FOG(G))
+#define WTF(G) *reinterpret_cast<const float4*>(pW + j * 1024 + FOG(G))
+    if (MM == MM_F16X3) {
+      SE3TN_MMA_SPLIT(PT, CT, PXF, WTF)
+    } else {
+      SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
+      SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
+      SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
+      SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
+    }
+#undef PXF
+#undef WTF
+#undef FOG
     if (kt + 1 < KT) wait_dma_and_barrier();
   }
 #undef ISSUE_TILE
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_splitk_kernel(const ConvArgs a
   }
 }
 
-template <int EPI>
+template <int EPI, int MM, int OUTF, int RESF>
 __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvArgs a, int cout, int total) {
   const int idx = blockIdx.x * 256 + threadIdx.x;  // (group, m, c4)
   if (idx >= total) return;
@@ -604,12 +610,24 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvArgs a, int 
     const float4 u = *reinterpret_cast<const float4*>(src + s * slice_stride);
     v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
   }
-  const int opix = padded_index(m, a.Ho * a.Wo, a.Wo);
+  if (MM == MM_F16X3) {
+    const float4 w = *reinterpret_cast<const float4*>(a.wscale + (size_t)g * a.bias_gs + c);
+    v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
+  }
+  const size_t opix = (size_t)padded_index(m, a.Ho * a.Wo, a.Wo);
   const float4 b = *reinterpret_cast<const float4*>(a.bias + (size_t)g * a.bias_gs + c);
   float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (EPI == 1) r = *reinterpret_cast<const float4*>(a.res + (size_t)g * a.res_gs + (size_t)opix * a.res_ld + c);
+  if (EPI == 1) {
+    const float* res = a.res + (size_t)g * a.res_gs;
+    r = (RESF == FMT_SPLIT) ? load_split4(res, opix, a.res_ld, c) : *reinterpret_cast<const float4*>(res + opix * a.res_ld + c);
+  }
   v = apply_epilogue<EPI>(v, b, r);
-  *reinterpret_cast<float4*>(a.out + (size_t)g * a.out_gs + (size_t)opix * a.out_ld + c) = v;
+  float* out = a.out + (size_t)g * a.out_gs;
+  if (OUTF == FMT_SPLIT) {
+    if (store_split4(out, opix, a.out_ld, c, v)) atomicOr(a.overflow, 1);
+  } else {
+    *reinterpret_cast<float4*>(out + opix * a.out_ld + c) = v;
+  }
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
@@ -649,11 +667,18 @@ static hipError_t launch_gather(const ConvArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int CIN, int STRIDE, int CT>
-static hipError_t launch_splitk(const ConvArgs& a, int epi, hipStream_t st) {
+template <int EPI, int MM, int OUTF, int RESF>
+static void launch_reduce(const ConvArgs& a, int cout, hipStream_t st) {
+  const int total = a.groups * a.M * (cout / 4);
+  hipLaunchKernelGGL((conv_reduce_kernel<EPI, MM, OUTF, RESF>), dim3((total + 255) / 256), dim3(256), 0, st, a, cout, total);
+}
+
+// outf / resf: FMT_* of the output and residual tensors (f16x3 mode: split rows except the last head conv)
+template <int CIN, int STRIDE, int CT, int MM>
+static hipError_t launch_splitk(const ConvArgs& a, int epi, int outf, int resf, hipStream_t st) {
   constexpr int BN = 64 * CT;
   constexpr size_t lds = (size_t)2 * (128 + BN) * 32 * sizeof(float);
-  auto kern = conv3x3_splitk_kernel<CIN, STRIDE, CT>;
+  auto kern = conv3x3_splitk_kernel<CIN, STRIDE, CT, MM>;
   static bool attr = false;
   hipError_t e = set_lds(kern, lds, attr);
   if (e != hipSuccess) return e;
@@ -662,11 +687,17 @@ static hipError_t launch_splitk(const ConvArgs& a, int epi, hipStream_t st) {
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int cout = a.tiles_n * BN;
-  const int total = a.groups * a.M * (cout / 4);
-  const dim3 grid((total + 255) / 256);
-  if (epi == 0) hipLaunchKernelGGL(conv_reduce_kernel<0>, grid, dim3(256), 0, st, a, cout, total);
-  else if (epi == 1) hipLaunchKernelGGL(conv_reduce_kernel<1>, grid, dim3(256), 0, st, a, cout, total);
-  else hipLaunchKernelGGL(conv_reduce_kernel<2>, grid, dim3(256), 0, st, a, cout, total);
+  if (MM == MM_F32) {
+    if (epi == 0) launch_reduce<0, MM_F32, FMT_F32, FMT_F32>(a, cout, st);
+    else if (epi == 1) launch_reduce<1, MM_F32, FMT_F32, FMT_F32>(a, cout, st);
+    else launch_reduce<2, MM_F32, FMT_F32, FMT_F32>(a, cout, st);
+  } else {
+    if (epi == 0) launch_reduce<0, MM_F16X3, FMT_SPLIT, FMT_F32>(a, cout, st);
+    else if (epi == 2) launch_reduce<2, MM_F16X3, FMT_SPLIT, FMT_F32>(a, cout, st);
+    else if (outf == FMT_SPLIT) launch_reduce<1, MM_F16X3, FMT_SPLIT, FMT_SPLIT>(a, cout, st);
+    else launch_reduce<1, MM_F16X3, FMT_F32, FMT_SPLIT>(a, cout, st);
+  }
+  (void)resf;
   return hipGetLastError();
 }
 
@@ -690,14 +721,23 @@ static int pick_slices(const ConvArgs& a, int cin, int cout, int big_tile_rows, 
 //   W = 44: 454 -> 464     W = 22: 378 -> 384     W = 11: 410 -> 424
 hipError_t launch_conv3x3(const ConvArgs& a0, int cin, int cout, int stride, int epi, hipStream_t st) {
   ConvArgs a = a0;
-  a.slices = a.fast ? 0 : pick_slices(a, cin, cout, stride == 1 ? 256 : 128, cout >= 128 ? 128 : 64);
+  a.slices = pick_slices(a, cin, cout, stride == 1 ? 256 : 128, cout >= 128 ? 128 : 64);
   if (a.slices > 0) {
     a.tiles_n = cout >= 128 ? cout / 128 : 1;
-    if (cin == 64 && stride == 1) return launch_splitk<64, 1, 1>(a, epi, st);
-    if (cin == 128 && stride == 2) return launch_splitk<128, 2, 2>(a, epi, st);
-    if (cin == 256 && stride == 1) return launch_splitk<256, 1, 2>(a, epi, st);
-    if (cin == 256 && stride == 2) return launch_splitk<256, 2, 2>(a, epi, st);
-    if (cin == 512 && stride == 1) return launch_splitk<512, 1, 2>(a, epi, st);
+    if (a.fast) {  // f16x3: split rows everywhere, float32 out of the last head conv (cin 512, residual)
+      const int outf = (cin == 512 && epi == 1) ? FMT_F32 : FMT_SPLIT;
+      if (cin == 64 && stride == 1) return launch_splitk<64, 1, 1, MM_F16X3>(a, epi, outf, FMT_SPLIT, st);
+      if (cin == 128 && stride == 2) return launch_splitk<128, 2, 2, MM_F16X3>(a, epi, outf, FMT_SPLIT, st);
+      if (cin == 256 && stride == 1) return launch_splitk<256, 1, 2, MM_F16X3>(a, epi, outf, FMT_SPLIT, st);
+      if (cin == 256 && stride == 2) return launch_splitk<256, 2, 2, MM_F16X3>(a, epi, outf, FMT_SPLIT, st);
+      if (cin == 512 && stride == 1) return launch_splitk<512, 1, 2, MM_F16X3>(a, epi, outf, FMT_SPLIT, st);
+      return hipErrorInvalidValue;
+    }
+    if (cin == 64 && stride == 1) return launch_splitk<64, 1, 1, MM_F32>(a, epi, FMT_F32, FMT_F32, st);
+    if (cin == 128 && stride == 2) return launch_splitk<128, 2, 2, MM_F32>(a, epi, FMT_F32, FMT_F32, st);
+    if (cin == 256 && stride == 1) return launch_splitk<256, 1, 2, MM_F32>(a, epi, FMT_F32, FMT_F32, st);
+    if (cin == 256 && stride == 2) return launch_splitk<256, 2, 2, MM_F32>(a, epi, FMT_F32, FMT_F32, st);
+    if (cin == 512 && stride == 1) return launch_splitk<512, 1, 2, MM_F32>(a, epi, FMT_F32, FMT_F32, st);
     return hipErrorInvalidValue;
   }
   if (a.fast) {

@@ -24,7 +24,7 @@ class StubRenderer:
         return self.rgb, self.depth
 
 
-def main(frames=300, faces_subdiv=None):
+def main(frames=300, faces_subdiv=None, f16x3=False):
     mean, std = Fx.mean_std(0)
     sd = {"state_dict": O.make_state_dict(0, head_gain=0.0005)}
     if faces_subdiv is None:
@@ -36,6 +36,9 @@ def main(frames=300, faces_subdiv=None):
         trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=150.0), mean, std, sd)
         trk.renderer = se3.HipRenderer(trk.engine, mesh)
         rdesc = "HIP rasteriser, %d faces, rendered A stays on the device" % len(mesh["faces"])
+    if f16x3:
+        trk.engine.set_precision(se3._lib.PREC_F16X3)
+        rdesc += ", SE3TN_PREC_F16X3"
     rgb, depth = Fx.synthetic_frame(3)
     P = Fx.pose(3)
     for _ in range(20):
@@ -61,3 +64,4 @@ def main(frames=300, faces_subdiv=None):
 if __name__ == "__main__":
     main()
     main(faces_subdiv=6)
+    main(faces_subdiv=6, f16x3=True)

@@ -254,12 +254,16 @@ def test_f16x3_mode_parity_and_overflow_guard(se3, model0):
         print("max |logit(f16x3) - logit(f32)| over 64 pairs = %.2e" % d)
         assert d < 2e-5
         assert float((o16["feature"] - f32).abs().max()) < 5e-6 * float(f32.abs().max()) + 1e-5
-        # n < 32: f16 stem + the float32 split-K convs -> agrees with PREC_F32 to f32 noise
-        eng.set_precision(se3._lib.PREC_F32)
-        a = model(Ac[:4], Bc[:4], return_feature=False)["trans"].clone()
-        eng.set_precision(se3._lib.PREC_F16X3)
-        b = model(Ac[:4], Bc[:4], return_feature=False)["trans"].clone()
-        assert float((a - b).abs().max()) < 2e-6
+        # small batches take the split-K kernels, also on the f16 matrix cores in this mode
+        for nn in (1, 4, 20):
+            eng.set_precision(se3._lib.PREC_F32)
+            a = model(Ac[:nn], Bc[:nn])
+            a_t, a_f = a["trans"].clone(), a["feature"].clone()
+            eng.set_precision(se3._lib.PREC_F16X3)
+            b = model(Ac[:nn], Bc[:nn])
+            assert float((a_t - b["trans"]).abs().max()) < 2e-6, nn
+            assert float((a_f - b["feature"]).abs().max()) < 5e-6 * float(a_f.abs().max()) + 1e-5, nn
+            assert not eng.overflow()
         # range guard: activations beyond the f16 range are reported, not silently wrong
         model(Ac * 3e4, Bc * 3e4, return_feature=False)
         assert eng.overflow()
