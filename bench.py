@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
                     help="f32 = exact float32 MFMA (default, the parity configuration); f16x3 = split-f16 MFMA for the "
                          "256/512-channel layers (float32-class error, see DESIGN.md)")
+    ap.add_argument("--winograd", type=int, default=None, metavar="MIN_BATCH",
+                    help="se3tn_set_winograd threshold (0 = direct kernels only; default: the library's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch time breakdown to stderr")
     args = ap.parse_args()
@@ -78,6 +80,8 @@ def main():
     eng.set_normalizers(0.03, 5 * np.pi / 180)
     if args.precision == "f16x3":
         eng.set_precision(se3._lib.PREC_F16X3)
+    if args.winograd is not None:
+        eng.set_winograd(args.winograd)
 
     # ---- synthetic inputs, resident in HBM (seeded per rank) -------------------------------
     g = torch.Generator(device=dev).manual_seed(1234 + rank)

@@ -80,6 +80,14 @@ int se3tn_set_normalization(se3tn_ctx* ctx, const double mean[8], const double s
 #define SE3TN_PREC_F16X3 1
 int se3tn_set_precision(se3tn_ctx* ctx, int mode);
 int se3tn_overflow(se3tn_ctx* ctx, int* flag); /* synchronises */
+/* Algorithm of the stride-1 256/512-channel convolutions (AB2.*, trans|rot conv2.*) in
+ * SE3TN_PREC_F32: batches of n >= min_batch pairs run them as Winograd F(2x2,3x3) -- float32 MFMA
+ * GEMMs on 16 transformed planes, 2.25x (22x22) / 1.89x (11x11) fewer multiplies; smaller batches and
+ * min_batch = 0 use the direct implicit-GEMM kernels.  Both are float32 arithmetic; they differ by
+ * rounding only (~1e-6 relative on those activations, like cuDNN's algorithm choice under
+ * torch.backends.cudnn.benchmark = True in the reference, predict.py:78). */
+#define SE3TN_WINOGRAD_DEFAULT_MIN_BATCH 32
+int se3tn_set_winograd(se3tn_ctx* ctx, int min_batch);
 /* trans_normalizer / rot_normalizer of Tracker.__init__ (predict.py:128). */
 int se3tn_set_normalizers(se3tn_ctx* ctx, double trans_normalizer, double rot_normalizer);
 

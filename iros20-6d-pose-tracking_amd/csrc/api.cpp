@@ -32,7 +32,7 @@ enum { MAX_LAUNCHES = 24, MAX_SLOTS = 64 };
 // one captured se3tn_infer: every argument that is baked into the kernel launches
 struct GraphKey {
   const void *A, *B, *trans, *rot, *poseA, *poseB, *blob;
-  int n, layout, prec;
+  int n, layout, prec, wino;
   double tn, rn;
   bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
 };
@@ -63,6 +63,11 @@ struct se3tn_ctx {
   float* logits = nullptr;                      // [mb,6]
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
   size_t part_bytes = 0;
+  // Winograd F(2x2,3x3) path (wino_mfma.hip) of convAB2.* and trans|rot conv2.* at n >= wino_min_batch
+  int wino_min_batch = SE3TN_WINOGRAD_DEFAULT_MIN_BATCH;  // 0 = never
+  float* wino_u[4] = {nullptr, nullptr, nullptr, nullptr};  // U = G g G^T of LAB2_1, LAB2_2, LH2_1, LH2_2
+  float *wino_v = nullptr, *wino_m = nullptr;   // [g][16][T][C] input tiles / per-frequency products
+  const float* wino_blob = nullptr;             // the blob wino_u was derived from
   int prec = SE3TN_PREC_F32;                    // se3tn_set_precision
   int in_split[2] = {0, 0};                     // pixel format currently held by inA / inB
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
@@ -91,6 +96,41 @@ struct se3tn_mesh {
   float4* vwin = nullptr;
   int V = 0, F = 0;
 };
+
+// ---- Winograd workspaces ----------------------------------------------------------------------------
+static const ConvId kWinoConvs[4] = {LAB2_1, LAB2_2, LH2_1, LH2_2};
+static int wino_slot(ConvId id) {
+  for (int i = 0; i < 4; ++i)
+    if (kWinoConvs[i] == id) return i;
+  return -1;
+}
+// V / M: the larger of the two layer shapes, floats per image: 16 x 36 tiles x 1024 ch | 16 x 121 x 256
+static size_t wino_ws_floats(int max_batch) {
+  const size_t head = (size_t)16 * 36 * 1024, ab = (size_t)16 * 121 * 256;
+  return (size_t)max_batch * (head > ab ? head : ab);
+}
+static int wino_prepare(se3tn_ctx* c, hipStream_t st) {
+  if (c->wino_min_batch <= 0 || c->max_batch < c->wino_min_batch) return SE3TN_OK;
+  if (!c->wino_v) {
+    HIPCHK(hipMalloc((void**)&c->wino_v, wino_ws_floats(c->max_batch) * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&c->wino_m, wino_ws_floats(c->max_batch) * sizeof(float)));
+    for (int i = 0; i < 4; ++i) {
+      const Conv3& s = conv_specs()[kWinoConvs[i]];
+      HIPCHK(hipMalloc((void**)&c->wino_u[i], (size_t)s.groups * 16 * s.cin * s.cout * sizeof(float)));
+    }
+  }
+  if (c->blob && c->wino_blob != c->blob) {
+    for (int i = 0; i < 4; ++i) {
+      const Conv3& s = conv_specs()[kWinoConvs[i]];
+      for (int g = 0; g < s.groups; ++g)
+        HIPCHK(launch_wino_weights(c->blob + c->L.conv_w[kWinoConvs[i]] + (size_t)g * conv3_words(s.cin, s.cout),
+                                   c->wino_u[i] + (size_t)g * 16 * s.cin * s.cout, s.cin, s.cout, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));  // init-time
+    c->wino_blob = c->blob;
+  }
+  return SE3TN_OK;
+}
 
 extern "C" {
 
@@ -153,7 +193,8 @@ void se3tn_destroy(se3tn_ctx* c) {
   if (!c) return;
   if (c->device >= 0) {
     float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
-                     c->head_t, c->head_f, c->logits, c->part, c->blob_owned};
+                     c->head_t, c->head_f, c->logits, c->part, c->blob_owned, c->wino_v, c->wino_m,
+                     c->wino_u[0], c->wino_u[1], c->wino_u[2], c->wino_u[3]};
     for (float* b : bufs)
       if (b) (void)hipFree(b);
     for (auto& g : c->graphs)
@@ -206,7 +247,8 @@ int se3tn_upload_weights(se3tn_ctx* c, void* stream) {
                         (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));  // init-time only: the host vector may go away
   c->blob = c->blob_owned;
-  return SE3TN_OK;
+  c->wino_blob = nullptr;  // same address, new contents
+  return wino_prepare(c, (hipStream_t)stream);
 }
 
 int se3tn_bind_weights(se3tn_ctx* c, const void* device_blob, size_t bytes) {
@@ -217,7 +259,15 @@ int se3tn_bind_weights(se3tn_ctx* c, const void* device_blob, size_t bytes) {
   if (hdr[0] != BLOB_MAGIC || hdr[1] != BLOB_VERSION || hdr[2] != (uint32_t)c->L.total)
     return fail(SE3TN_E_SHAPE, "se3tn_bind_weights: bad blob header");
   c->blob = (const float*)device_blob;
-  return SE3TN_OK;
+  c->wino_blob = nullptr;
+  return wino_prepare(c, nullptr);
+}
+
+int se3tn_set_winograd(se3tn_ctx* c, int min_batch) {
+  if (!c || min_batch < 0) return fail(SE3TN_E_ARG, "se3tn_set_winograd: bad argument");
+  c->wino_min_batch = min_batch;
+  if (c->device < 0) return SE3TN_OK;
+  return wino_prepare(c, nullptr);
 }
 
 int se3tn_set_normalization(se3tn_ctx* c, const double mean[8], const double stdv[8]) {
@@ -304,7 +354,7 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
   GraphKey key;
   std::memset(&key, 0, sizeof(key));
   key.A = A; key.B = B; key.trans = trans; key.rot = rot; key.poseA = poseA; key.poseB = poseB; key.blob = c->blob;
-  key.n = n; key.layout = layout; key.prec = c->prec; key.tn = c->tn; key.rn = c->rn;
+  key.n = n; key.layout = layout; key.prec = c->prec; key.wino = c->wino_min_batch; key.tn = c->tn; key.rn = c->rn;
   hipStream_t st = (hipStream_t)stream;
   for (auto& g : c->graphs) {
     if (!(g.key == key)) continue;
@@ -390,6 +440,21 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
   auto conv = [&](ConvId id, const float* in, int in_ld, int in_gs, const float* res, int res_ld, int res_gs,
                   float* out, int out_ld, int out_gs, int hin, int stride, int epi, const char* name) -> int {
     const Conv3& s = conv_specs()[id];
+    const int ws = wino_slot(id);
+    if (ws >= 0 && !fast && c->wino_min_batch > 0 && n >= c->wino_min_batch && c->wino_v) {
+      WinoArgs w{};
+      w.in = in; w.U = c->wino_u[ws]; w.bias = W + L.conv_b[id]; w.res = res; w.out = out;
+      w.V = c->wino_v; w.Mw = c->wino_m;
+      w.in_ld = in_ld; w.res_ld = res_ld; w.out_ld = out_ld;
+      w.H = hin; w.W = hin; w.th = (hin + 1) / 2; w.tw = w.th;
+      w.n = n; w.T = n * w.th * w.tw;
+      w.C = s.cin; w.Cout = s.cout; w.groups = s.groups;
+      w.in_gs = in_gs; w.res_gs = res_gs; w.out_gs = out_gs; w.bias_gs = s.cout;
+      w.u_gs = (long long)16 * s.cin * s.cout;
+      hipError_t e = launch_wino_conv(w, epi, st);
+      if (e != hipSuccess) return hipfail(e, name);
+      return prof_mark(c, st, name, true);
+    }
     ConvArgs a{};
     a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id];
     if (fast) {

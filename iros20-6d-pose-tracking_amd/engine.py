@@ -90,6 +90,11 @@ class Engine:
         """_lib.PREC_F32 (default, exact) or _lib.PREC_F16X3 (split-f16 MFMA for the deep layers, n >= 32)."""
         check(self.lib.se3tn_set_precision(self._h, int(mode)), "se3tn_set_precision")
 
+    def set_winograd(self, min_batch):
+        """Batches of n >= min_batch run the 256/512-channel stride-1 convs as Winograd F(2x2,3x3)
+        (float32); 0 = always the direct kernels.  Default: SE3TN_WINOGRAD_DEFAULT_MIN_BATCH."""
+        check(self.lib.se3tn_set_winograd(self._h, int(min_batch)), "se3tn_set_winograd")
+
     def overflow(self):
         """True if a split-row store left the f16 range since the last call (synchronises)."""
         f = C.c_int(0)

@@ -140,6 +140,55 @@ def test_batch64_rows_equal_batch1_and_ragged_tail(se3, model0):
     _close("b64 rot", r64[[3, 40]].cpu(), ref["rot"], 0, NET_TOL)
 
 
+def test_winograd_path_vs_direct_and_oracle(se3, golden_dir):
+    """The large-batch algorithm of the 256/512-channel residual blocks (Winograd F(2x2,3x3), float32)
+    forced on at small n: every stage against the oracle and the reference-made golden, and against
+    the direct kernels on the same engine.  n=3 and n=5 make every GEMM row tile ragged (T = 108 / 363
+    / 180 / 605 rows); 11x11 maps exercise the dropped 12th row / column of the 6x6 tiling."""
+    sd = O.make_state_dict(0)
+    m = se3.Se3TrackNet(176, max_batch=8)
+    m.load_state_dict(sd)
+    m.cuda(0).eval()
+    eng = m.engine
+    g = np.load(os.path.join(golden_dir, "network_n3.npz"))
+    A, B = Fx.net_inputs(1, 3)
+    ref = O.forward(sd, A, B, intermediates=True)
+    eng.set_winograd(0)
+    od = m(A.cuda(), B.cuda())
+    feat_d, head_d = od["feature"].cpu().clone(), _nchw(eng.debug_buffer("head", 3), 1).clone()
+    lg_d = eng.logits(3).cpu().clone()
+    eng.set_winograd(1)
+    ow = m(A.cuda(), B.cuda())
+    feat_w, head_w = ow["feature"].cpu(), _nchw(eng.debug_buffer("head", 3), 1)   # _nchw: borders still zero
+    lg_w = eng.logits(3).cpu()
+    assert not torch.equal(head_w, head_d), "the Winograd path did not run"
+    WINO_SCALE = 2e-5   # transform-amplified f32 rounding, relative to the layer's largest activation
+    _close("feature", feat_w, ref["feature"], ACT_RTOL, 0, WINO_SCALE)
+    _close("trans_conv2", head_w[:, :512], ref["trans_c2"], ACT_RTOL, 0, WINO_SCALE)
+    _close("rot_conv2", head_w[:, 512:], ref["rot_c2"], ACT_RTOL, 0, WINO_SCALE)
+    _close("feature vs direct", feat_w, feat_d, ACT_RTOL, 0, WINO_SCALE)
+    _close("head vs direct", head_w, head_d, ACT_RTOL, 0, WINO_SCALE)
+    e0 = _close("logits vs direct", lg_w, lg_d, 0, 2e-5)
+    _close("trans_logit", lg_w[:, :3], ref["trans_logit"], 0, NET_TOL)
+    _close("rot_logit", lg_w[:, 3:], ref["rot_logit"], 0, NET_TOL)
+    _close("trans vs golden", ow["trans"].cpu(), torch.from_numpy(g["trans"]), 0, NET_TOL)
+    _close("rot vs golden", ow["rot"].cpu(), torch.from_numpy(g["rot"]), 0, NET_TOL)
+    _close("feature vs golden", feat_w[:, ::SUB, ::SUB, ::SUB], torch.from_numpy(g["feature"]), ACT_RTOL, 0, WINO_SCALE)
+    # ragged n, and the zero borders of every buffer the output transform writes stay zero
+    A5, B5 = Fx.net_inputs(9, 5)
+    o5 = m(A5.cuda(), B5.cuda(), return_feature=False)
+    t5, r5 = o5["trans"].cpu().clone(), o5["rot"].cpu().clone()
+    for name in ("ab", "ab_t", "head", "head_t"):
+        _nchw(eng.debug_buffer(name, 5), 1)
+    ref5 = O.forward(sd, A5, B5)
+    _close("n5 trans", t5, ref5["trans"], 0, NET_TOL)
+    _close("n5 rot", r5, ref5["rot"], 0, NET_TOL)
+    eng.set_winograd(0)
+    o5d = m(A5.cuda(), B5.cuda(), return_feature=False)
+    e1 = _close("n5 trans vs direct", t5, o5d["trans"].cpu(), 0, 2e-5)
+    print("max |d logit| Winograd vs direct = %.2e, |d trans| = %.2e" % (e0, e1))
+
+
 def _frame_to_cuda(rgb, depth):
     return torch.from_numpy(rgb).cuda(), torch.from_numpy(depth.view(np.int16)).cuda()
 
