@@ -42,6 +42,7 @@ def main():
                          "256/512-channel layers (float32-class error, see DESIGN.md)")
     ap.add_argument("--winograd", type=int, default=None, metavar="MIN_BATCH",
                     help="se3tn_set_winograd threshold (0 = direct kernels only; default: the library's)")
+    ap.add_argument("--winograd-tile", type=int, default=0, choices=[0, 2, 4], help="F(tile x tile,3x3); 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch time breakdown to stderr")
     args = ap.parse_args()
@@ -80,8 +81,8 @@ def main():
     eng.set_normalizers(0.03, 5 * np.pi / 180)
     if args.precision == "f16x3":
         eng.set_precision(se3._lib.PREC_F16X3)
-    if args.winograd is not None:
-        eng.set_winograd(args.winograd)
+    if args.winograd is not None or args.winograd_tile:
+        eng.set_winograd(args.winograd if args.winograd is not None else 8, args.winograd_tile)
 
     # ---- synthetic inputs, resident in HBM (seeded per rank) -------------------------------
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -149,6 +150,16 @@ def main():
         conv_ms.append(c); tot_ms.append(t)
     conv_ms_avg = float(np.mean(conv_ms))
     achieved = CONV3_FLOP_PER_PAIR * nb / (conv_ms_avg * 1e-3) / 1e12
+    # MFMA flops the conv family actually executes: the Winograd layers do (tile+2)^2 multiplies per
+    # tile x tile outputs (incl. the rows / columns computed past the map edge) instead of 9 per output
+    wino_min, wino_tile = eng.get_winograd()
+    wino_on = args.precision == "f32" and wino_min > 0 and nb >= wino_min
+    executed_per_pair = CONV3_FLOP_PER_PAIR
+    if wino_on:
+        nf = (wino_tile + 2) ** 2
+        for hw, cin, cout, convs in ((22, 256, 256, 2), (11, 512, 512, 4)):   # AB2.conv1/2; trans|rot conv2.conv1/2
+            tiles = (-(-hw // wino_tile)) ** 2
+            executed_per_pair += convs * 2 * cin * cout * (nf * tiles - 9 * hw * hw)
     layers = eng.profile_launches(slots - 1)
     eng.profile_enable(0)
     pose_main = poseB.clone()
@@ -186,11 +197,21 @@ def main():
                        "pairs_per_gpu": nb, "global_batch": world * nb, "stage": args.stage,
                        "parallelism": "frame-sharded x%d, RCCL weight broadcast + pose all-gather" % world},
             "tflops_total": round(value * FLOP_PER_PAIR / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_slab_kernel + conv3x3_gather_s2_kernel (10 launches/step, exact-f32 v_mfma_f32_32x32x2_f32)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "3x3 conv family, 10 convs/step on exact-f32 v_mfma_f32_32x32x2_f32: direct implicit GEMM "
+                                   "(conv3x3_slab_kernel, conv3x3_gather_s2_kernel)" +
+                                   (" + Winograd F(%dx%d,3x3) for AB2.* and trans|rot conv2.* (wino_input/gemm/output_kernel)"
+                                    % (wino_tile, wino_tile) if wino_on else ""),
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                          "conv_ms_per_step": round(conv_ms_avg, 4), "all_kernels_ms_per_step": round(float(np.mean(tot_ms)), 4),
-                         "flop_per_step": CONV3_FLOP_PER_PAIR * nb},
+                         "flop_per_step": CONV3_FLOP_PER_PAIR * nb,
+                         # achieved / frac count the ALGORITHMIC (direct-convolution) flops of SURVEY.md 8(d); with the
+                         # Winograd layers the matrix cores execute fewer, so frac may exceed 1 -- the *_executed
+                         # pair is what the MFMA pipes really sustain (transform passes included in the time)
+                         "flop_per_step_executed": executed_per_pair * nb,
+                         "achieved_executed": round(executed_per_pair * nb / (conv_ms_avg * 1e-3) / 1e12, 2),
+                         "frac_executed": round(executed_per_pair * nb / (conv_ms_avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             "layers_ms": {n: round(ms, 4) for n, ms in layers},
         }
         if other is not None:
@@ -220,7 +241,11 @@ def pmc_traffic(nb):
     d = json.load(open(files[-1]))
     # launches per step of each instantiation: 64-ch kernels run twice (grouped A|B pair + B3 alone)
     total = 0.0
+    wino_calls = {"wino_input_kernel": 4, "wino_gemm_kernel": 2, "wino_output_kernel": 2}   # per instantiation
     for k, v in d["fetch"].items():
+        if k.startswith("wino_") and k.split("<")[0] in wino_calls:
+            total += wino_calls[k.split("<")[0]] * (2.0 * v["FETCH_SIZE"] + d["write"][k]["WRITE_SIZE"]) * 1024.0
+            continue
         if not k.startswith("conv3x3") or "<" not in k:
             continue
         targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]

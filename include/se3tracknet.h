@@ -81,13 +81,16 @@ int se3tn_set_normalization(se3tn_ctx* ctx, const double mean[8], const double s
 int se3tn_set_precision(se3tn_ctx* ctx, int mode);
 int se3tn_overflow(se3tn_ctx* ctx, int* flag); /* synchronises */
 /* Algorithm of the stride-1 256/512-channel convolutions (AB2.*, trans|rot conv2.*) in
- * SE3TN_PREC_F32: batches of n >= min_batch pairs run them as Winograd F(2x2,3x3) -- float32 MFMA
- * GEMMs on 16 transformed planes, 2.25x (22x22) / 1.89x (11x11) fewer multiplies; smaller batches and
- * min_batch = 0 use the direct implicit-GEMM kernels.  Both are float32 arithmetic; they differ by
- * rounding only (~1e-6 relative on those activations, like cuDNN's algorithm choice under
- * torch.backends.cudnn.benchmark = True in the reference, predict.py:78). */
-#define SE3TN_WINOGRAD_DEFAULT_MIN_BATCH 32
-int se3tn_set_winograd(se3tn_ctx* ctx, int min_batch);
+ * SE3TN_PREC_F32: batches of n >= min_batch pairs run them as Winograd F(tile x tile, 3x3), tile = 2 | 4
+ * (0 keeps the current tile) -- float32 MFMA GEMMs on (tile+2)^2 transformed planes, 2.25x / 4x fewer
+ * multiplies per output; smaller batches and min_batch = 0 use the direct implicit-GEMM kernels.
+ * All are float32 arithmetic and differ by rounding only (rms error of one layer relative to its
+ * largest activation: direct 5e-8, tile 2 1.5e-7, tile 4 6e-7; the logits move by ~1e-6) -- the same
+ * freedom cuDNN takes under torch.backends.cudnn.benchmark = True in the reference (predict.py:78). */
+#define SE3TN_WINOGRAD_DEFAULT_MIN_BATCH 6
+#define SE3TN_WINOGRAD_DEFAULT_TILE 4
+int se3tn_set_winograd(se3tn_ctx* ctx, int min_batch, int tile);
+int se3tn_get_winograd(const se3tn_ctx* ctx, int* min_batch, int* tile);
 /* trans_normalizer / rot_normalizer of Tracker.__init__ (predict.py:128). */
 int se3tn_set_normalizers(se3tn_ctx* ctx, double trans_normalizer, double rot_normalizer);
 

@@ -63,8 +63,10 @@ struct se3tn_ctx {
   float* logits = nullptr;                      // [mb,6]
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
   size_t part_bytes = 0;
-  // Winograd F(2x2,3x3) path (wino_mfma.hip) of convAB2.* and trans|rot conv2.* at n >= wino_min_batch
+  // Winograd F(m x m,3x3) path (wino_mfma.hip) of convAB2.* and trans|rot conv2.* at n >= wino_min_batch
   int wino_min_batch = SE3TN_WINOGRAD_DEFAULT_MIN_BATCH;  // 0 = never
+  int wino_tile = SE3TN_WINOGRAD_DEFAULT_TILE;            // m = 2 | 4
+  int wino_tile_derived = 0;                              // the m wino_u was derived for
   float* wino_u[4] = {nullptr, nullptr, nullptr, nullptr};  // U = G g G^T of LAB2_1, LAB2_2, LH2_1, LH2_2
   float *wino_v = nullptr, *wino_m = nullptr;   // [g][16][T][C] input tiles / per-frequency products
   const float* wino_blob = nullptr;             // the blob wino_u was derived from
@@ -104,7 +106,7 @@ static int wino_slot(ConvId id) {
     if (kWinoConvs[i] == id) return i;
   return -1;
 }
-// V / M: the larger of the two layer shapes, floats per image: 16 x 36 tiles x 1024 ch | 16 x 121 x 256
+// V / M: the largest layer shape over m = 2 | 4, floats per image: (m=2) 16 x 36 tiles x 1024 ch | 16 x 121 x 256
 static size_t wino_ws_floats(int max_batch) {
   const size_t head = (size_t)16 * 36 * 1024, ab = (size_t)16 * 121 * 256;
   return (size_t)max_batch * (head > ab ? head : ab);
@@ -116,18 +118,20 @@ static int wino_prepare(se3tn_ctx* c, hipStream_t st) {
     HIPCHK(hipMalloc((void**)&c->wino_m, wino_ws_floats(c->max_batch) * sizeof(float)));
     for (int i = 0; i < 4; ++i) {
       const Conv3& s = conv_specs()[kWinoConvs[i]];
-      HIPCHK(hipMalloc((void**)&c->wino_u[i], (size_t)s.groups * 16 * s.cin * s.cout * sizeof(float)));
+      HIPCHK(hipMalloc((void**)&c->wino_u[i], (size_t)s.groups * 36 * s.cin * s.cout * sizeof(float)));
     }
   }
-  if (c->blob && c->wino_blob != c->blob) {
+  if (c->blob && (c->wino_blob != c->blob || c->wino_tile_derived != c->wino_tile)) {
+    const int nf = (c->wino_tile + 2) * (c->wino_tile + 2);
     for (int i = 0; i < 4; ++i) {
       const Conv3& s = conv_specs()[kWinoConvs[i]];
       for (int g = 0; g < s.groups; ++g)
         HIPCHK(launch_wino_weights(c->blob + c->L.conv_w[kWinoConvs[i]] + (size_t)g * conv3_words(s.cin, s.cout),
-                                   c->wino_u[i] + (size_t)g * 16 * s.cin * s.cout, s.cin, s.cout, st));
+                                   c->wino_u[i] + (size_t)g * nf * s.cin * s.cout, s.cin, s.cout, c->wino_tile, st));
     }
     HIPCHK(hipStreamSynchronize(st));  // init-time
     c->wino_blob = c->blob;
+    c->wino_tile_derived = c->wino_tile;
   }
   return SE3TN_OK;
 }
@@ -263,11 +267,20 @@ int se3tn_bind_weights(se3tn_ctx* c, const void* device_blob, size_t bytes) {
   return wino_prepare(c, nullptr);
 }
 
-int se3tn_set_winograd(se3tn_ctx* c, int min_batch) {
-  if (!c || min_batch < 0) return fail(SE3TN_E_ARG, "se3tn_set_winograd: bad argument");
+int se3tn_set_winograd(se3tn_ctx* c, int min_batch, int tile) {
+  if (!c || min_batch < 0 || (tile != 0 && tile != 2 && tile != 4))
+    return fail(SE3TN_E_ARG, "se3tn_set_winograd: min_batch >= 0 and tile in {0, 2, 4}");
   c->wino_min_batch = min_batch;
+  if (tile) c->wino_tile = tile;
   if (c->device < 0) return SE3TN_OK;
   return wino_prepare(c, nullptr);
+}
+
+int se3tn_get_winograd(const se3tn_ctx* c, int* min_batch, int* tile) {
+  if (!c || !min_batch || !tile) return fail(SE3TN_E_ARG, "se3tn_get_winograd: bad argument");
+  *min_batch = c->wino_min_batch;
+  *tile = c->wino_tile;
+  return SE3TN_OK;
 }
 
 int se3tn_set_normalization(se3tn_ctx* c, const double mean[8], const double stdv[8]) {
@@ -354,7 +367,7 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
   GraphKey key;
   std::memset(&key, 0, sizeof(key));
   key.A = A; key.B = B; key.trans = trans; key.rot = rot; key.poseA = poseA; key.poseB = poseB; key.blob = c->blob;
-  key.n = n; key.layout = layout; key.prec = c->prec; key.wino = c->wino_min_batch; key.tn = c->tn; key.rn = c->rn;
+  key.n = n; key.layout = layout; key.prec = c->prec; key.wino = c->wino_min_batch * 8 + c->wino_tile; key.tn = c->tn; key.rn = c->rn;
   hipStream_t st = (hipStream_t)stream;
   for (auto& g : c->graphs) {
     if (!(g.key == key)) continue;
@@ -446,11 +459,12 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
       w.in = in; w.U = c->wino_u[ws]; w.bias = W + L.conv_b[id]; w.res = res; w.out = out;
       w.V = c->wino_v; w.Mw = c->wino_m;
       w.in_ld = in_ld; w.res_ld = res_ld; w.out_ld = out_ld;
-      w.H = hin; w.W = hin; w.th = (hin + 1) / 2; w.tw = w.th;
+      w.m = c->wino_tile; w.nf = (w.m + 2) * (w.m + 2);
+      w.H = hin; w.W = hin; w.th = (hin + w.m - 1) / w.m; w.tw = w.th;
       w.n = n; w.T = n * w.th * w.tw;
       w.C = s.cin; w.Cout = s.cout; w.groups = s.groups;
       w.in_gs = in_gs; w.res_gs = res_gs; w.out_gs = out_gs; w.bias_gs = s.cout;
-      w.u_gs = (long long)16 * s.cin * s.cout;
+      w.u_gs = (long long)w.nf * s.cin * s.cout;
       hipError_t e = launch_wino_conv(w, epi, st);
       if (e != hipSuccess) return hipfail(e, name);
       return prof_mark(c, st, name, true);

@@ -129,18 +129,19 @@ struct ConvArgs {
   int fast;
 };
 
-// Winograd F(2x2,3x3) path of the stride-1 256/512-channel convs at large batch (wino_mfma.hip)
+// Winograd F(m x m,3x3) path of the stride-1 256/512-channel convs at large batch (wino_mfma.hip)
 struct WinoArgs {
   const float* in;    // padded NHWC input, channel offset of group 0 applied
-  const float* U;     // transformed weights of group 0: [chunk][16][Cout][32]
+  const float* U;     // transformed weights of group 0: [chunk][nf][Cout][32]
   const float* bias;
   const float* res;   // residual or nullptr
   float* out;         // padded NHWC
-  float* V;           // workspace [groups][16][T][C]     (transformed input tiles)
-  float* Mw;          // workspace [groups][16][T][Cout]  (per-frequency products)
+  float* V;           // workspace [groups][nf][T][C]     (transformed input tiles)
+  float* Mw;          // workspace [groups][nf][T][Cout]  (per-frequency products)
   int in_ld, res_ld, out_ld;
   int H, W;           // interior size (input == output, stride 1)
-  int th, tw;         // 2x2-output tiles per image: ceil(H/2), ceil(W/2)
+  int m, nf;          // output tile edge (2 | 4), nf = (m+2)^2 frequencies
+  int th, tw;         // m x m output tiles per image: ceil(H/m), ceil(W/m)
   int n, T;           // images, T = n * th * tw
   int C, Cout, groups;
   int in_gs, res_gs, out_gs, bias_gs;
@@ -170,10 +171,10 @@ hipError_t launch_stem(const float* inA, const float* inB, const float* w, const
 hipError_t launch_maxpool(const float* in, float* out, int n, int split_out, hipStream_t st);
 // conv3x3: cin/cout/stride select the instantiation; epi: 0 bias+relu, 1 bias+res+relu, 2 bias+selu
 hipError_t launch_conv3x3(const ConvArgs& a, int cin, int cout, int stride, int epi, hipStream_t st);
-// Winograd F(2x2,3x3): U = G g G^T (float64, rounded once) from the packed direct weights
-// [chunk][9][cout][32] -> [chunk][16][cout][32]; launch_wino_conv = input transform + 16 x groups
+// Winograd F(m x m,3x3): U = G g G^T (float64, rounded once) from the packed direct weights
+// [chunk][9][cout][32] -> [chunk][(m+2)^2][cout][32]; launch_wino_conv = input transform + nf x groups
 // batched MFMA GEMMs + output transform with the conv epilogue (epi 0 | 1)
-hipError_t launch_wino_weights(const float* packed, float* U, int cin, int cout, hipStream_t st);
+hipError_t launch_wino_weights(const float* packed, float* U, int cin, int cout, int m, hipStream_t st);
 hipError_t launch_wino_conv(const WinoArgs& a, int epi, hipStream_t st);
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,

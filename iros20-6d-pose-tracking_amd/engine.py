@@ -90,10 +90,17 @@ class Engine:
         """_lib.PREC_F32 (default, exact) or _lib.PREC_F16X3 (split-f16 MFMA for the deep layers, n >= 32)."""
         check(self.lib.se3tn_set_precision(self._h, int(mode)), "se3tn_set_precision")
 
-    def set_winograd(self, min_batch):
-        """Batches of n >= min_batch run the 256/512-channel stride-1 convs as Winograd F(2x2,3x3)
-        (float32); 0 = always the direct kernels.  Default: SE3TN_WINOGRAD_DEFAULT_MIN_BATCH."""
-        check(self.lib.se3tn_set_winograd(self._h, int(min_batch)), "se3tn_set_winograd")
+    def set_winograd(self, min_batch, tile=0):
+        """Batches of n >= min_batch run the 256/512-channel stride-1 convs as Winograd F(tile x tile,3x3)
+        (float32; tile 2 | 4, 0 = keep); min_batch 0 = always the direct kernels.  Defaults:
+        SE3TN_WINOGRAD_DEFAULT_MIN_BATCH / _TILE of include/se3tracknet.h."""
+        check(self.lib.se3tn_set_winograd(self._h, int(min_batch), int(tile)), "se3tn_set_winograd")
+
+    def get_winograd(self):
+        """(min_batch, tile) currently in force."""
+        mb, t = C.c_int(), C.c_int()
+        check(self.lib.se3tn_get_winograd(self._h, C.byref(mb), C.byref(t)), "se3tn_get_winograd")
+        return mb.value, t.value
 
     def overflow(self):
         """True if a split-row store left the f16 range since the last call (synchronises)."""
