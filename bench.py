@@ -165,7 +165,7 @@ def main():
     pose_main = poseB.clone()
     # second arithmetic mode on the same inputs: timed the same way, reported beside the main value
     other = None
-    if args.precision == "f32" and nb >= 32 and not os.environ.get("SE3TN_NO_ALT"):
+    if args.precision == "f32" and nb >= 32 and args.stage == "full" and not os.environ.get("SE3TN_NO_ALT"):
         eng.set_precision(se3._lib.PREC_F16X3)
         for _ in range(args.warmup):
             step()
@@ -182,6 +182,23 @@ def main():
                  "max_abs_pose_diff_vs_f32": float((poseB - pose_main).abs().max()),
                  "range_guard_fired": bool(eng.overflow())}
         eng.set_precision(se3._lib.PREC_F32)
+    # and the same float32 run with the Winograd layers switched back to the direct kernels
+    direct = None
+    if wino_on and not os.environ.get("SE3TN_NO_ALT"):
+        eng.set_winograd(0)
+        for _ in range(args.warmup):
+            step()
+        eng.profile_enable(slots)
+        dt3 = timed_loop(args.steps)
+        c3 = float(np.mean([eng.profile_read(s_)[0] for s_ in range(slots)]))
+        eng.profile_enable(0)
+        direct = {"algorithm": "direct implicit GEMM for all ten 3x3 convs (se3tn_set_winograd(ctx, 0, 0))",
+                  "value": round(world * nb * args.steps / dt3, 1), "unit": "pairs/s", "ms_per_step": round(dt3 / args.steps * 1e3, 4),
+                  "conv_ms_per_step": round(c3, 4),
+                  "achieved": round(CONV3_FLOP_PER_PAIR * nb / (c3 * 1e-3) / 1e12, 2),
+                  "frac": round(CONV3_FLOP_PER_PAIR * nb / (c3 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                  "max_abs_pose_diff_vs_main": float((poseB - pose_main).abs().max())}
+        eng.set_winograd(wino_min, wino_tile)
     assert os.environ.get("SE3TN_NOCHECK") or torch.isfinite(poseB).all()
     assert os.environ.get("SE3TN_NOCHECK") or not eng.overflow(), "f16x3 range guard fired"
 
@@ -216,6 +233,8 @@ def main():
         }
         if other is not None:
             out["alt_precision"] = other
+        if direct is not None:
+            out["alt_algorithm"] = direct
         tr, src = pmc_traffic(nb)
         if tr is not None:
             out["roofline"]["traffic"] = int(tr)
