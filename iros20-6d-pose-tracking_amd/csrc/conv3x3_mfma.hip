@@ -36,6 +36,10 @@
 //    tap (strided windows have no contiguous slab).
 #include "mfma_common.h"
 
+#ifndef SE3TN_PERSISTENT_SLAB
+#define SE3TN_PERSISTENT_SLAB 1  // 0: one workgroup per tile (A/B timing only)
+#endif
+
 namespace se3tn {
 
 // shared epilogue: lane holds pixel l31 x couts {8q + 4hh + 0..3} of each 32x32 tile.
@@ -96,30 +100,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_slab_kernel(const ConvArgs a) 
   const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, hh = lane >> 5;
 
+  // PERSISTENT tiles: workgroup b handles tiles b, b + gridDim.x, ...; gridDim.x is a multiple of `panels`
+  // (or the whole tile count), so a workgroup keeps its weight panel and the panel <-> XCD affinity.
+  // The next tile's first slab and weight tile are DMA'd during the last chunk of the current one, and
+  // the epilogue's stores drain under the next tile's first K-steps: no per-tile prologue / epilogue bubble.
   const int panels = a.groups * a.tiles_n;
-  const int p = blockIdx.x % panels, mt = blockIdx.x / panels;
+  const int ntiles = ((a.M + BM - 1) / BM) * panels;
+  const int p = blockIdx.x % panels;
   const int g = p / a.tiles_n, nt = p % a.tiles_n;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int n0 = nt * BN;
   const float* __restrict__ in = a.in + (size_t)g * a.in_gs;
   const float* __restrict__ wgt = a.w + (size_t)g * a.w_gs + (size_t)n0 * 32;
   const int W = a.W, Wp = W + 2, HW = a.H * W;
+  static_assert(NCH % 2 == 0, "chunk 0 of the next tile reuses slab buffer 0 during the last chunk");
 
-  // slab = padded-flat pixels [lo, lo + 8 * npieces) covering the tile's pixels +- (Wp + 1)
-  const int mlast = min(m0 + BM, a.M) - 1;
-  const int lo = padded_index(m0, HW, W) - (Wp + 1);
-  const int npieces = min((padded_index(mlast, HW, W) + (Wp + 1) + 1 - lo + 7) >> 3, SLABPX / 8);
-
-  // per-lane pixel rows of this wave's tiles
-  int ibase[PT];  // slab index of the pixel at the centre tap
-  int opix[PT];   // padded-flat index in the output / residual tensor (same geometry as the input)
-  bool ok[PT];
-#pragma unroll
-  for (int i = 0; i < PT; ++i) {
-    const int m = m0 + (wm * PT + i) * 32 + l31;
-    ok[i] = m < a.M;
-    opix[i] = padded_index(ok[i] ? m : mlast, HW, W);
-    ibase[i] = opix[i] - lo;
+  // slab of pixel tile mt = padded-flat pixels [lo, lo + 8 * npieces) covering the tile's pixels +- (Wp + 1)
+#define TILE_GEOMETRY(MT, LO, NP)                                                                     \
+  {                                                                                                  \
+    const int m0_ = (MT) * BM, ml_ = min(m0_ + BM, a.M) - 1;                                          \
+    LO = padded_index(m0_, HW, W) - (Wp + 1);                                                         \
+    NP = min((padded_index(ml_, HW, W) + (Wp + 1) + 1 - LO + 7) >> 3, SLABPX / 8);                    \
   }
+  int tile = blockIdx.x;
+  int lo, npieces;
+  TILE_GEOMETRY(tile / panels, lo, npieces)
 
   // ---- DMA geometry ---------------------------------------------------------------------------
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
@@ -132,11 +136,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_slab_kernel(const ConvArgs a) 
   const unsigned wv_odd = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ ((4 + (lane >> 4)) & 7)) << 4));
 
   // slab piece wid + 8 T of chunk CH into slab buffer SB (this wave owns pieces wid + 8 t, t = 0..8)
-#define SLAB_PIECE(CH, SB, T)                                                                        \
+#define SLAB_PIECE(LO, NP, CH, SB, T)                                                                \
   {                                                                                                  \
     const int j_ = wid + 8 * (T);                                                                    \
-    if (j_ < npieces) {                                                                              \
-      const float* sb_ = in + (size_t)(lo + 8 * j_) * a.in_ld + (CH) * 32;                            \
+    if (j_ < (NP)) {                                                                                 \
+      const float* sb_ = in + (size_t)((LO) + 8 * j_) * a.in_ld + (CH) * 32;                          \
       glds16<0>(sb_, (j_ & 1) ? sv_odd : sv_even, lds0 + (unsigned)(((SB) * SLAB + j_ * 256) * 4));  \
     }                                                                                                \
   }
@@ -159,63 +163,95 @@ __global__ __launch_bounds__(512, 2) void conv3x3_slab_kernel(const ConvArgs a) 
   const int fo0 = ((0 ^ xk) << 3) + wlo, fo1 = ((1 ^ xk) << 3) + wlo, fo2 = ((2 ^ xk) << 3) + wlo,
             fo3 = ((3 ^ xk) << 3) + wlo;
 
-  f32x16 acc[PT][CT];
+  // prologue of the first tile: whole slab of chunk 0 + first weight tile
 #pragma unroll
-  for (int i = 0; i < PT; ++i)
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // prologue: whole slab of chunk 0 + first weight tile
-#pragma unroll
-  for (int t = 0; t < 9; ++t) SLAB_PIECE(0, 0, t)
+  for (int t = 0; t < 9; ++t) SLAB_PIECE(lo, npieces, 0, 0, t)
   WEIGHT_TILE(0, 0, 0)
   wait_dma_and_barrier();
 
-  int kt = 0;
-  for (int ch = 0; ch < NCH; ++ch) {
-    const int sb = ch & 1;
-    for (int tap = 0; tap < 9; ++tap, ++kt) {
-      const int wb = kt & 1;
-      // next K-step's weights, and this wave's share of the next chunk's slab
-      if (tap < 8) {
-        WEIGHT_TILE(ch, tap + 1, wb ^ 1)
-      } else if (ch + 1 < NCH) {
-        WEIGHT_TILE(ch + 1, 0, wb ^ 1)
-      }
-      if (ch + 1 < NCH) SLAB_PIECE(ch + 1, sb ^ 1, tap)
-
-      const int r = tap / 3, s = tap - r * 3;
-      const int tapoff = (r - 1) * Wp + (s - 1);
-      // pixel fragment addresses: slab row idx = ibase + tapoff, slot (2 kg + hh) ^ ((idx >> 1) & 7),
-      // i.e. float offset (8 kg) ^ py with py = (hh ^ ((idx >> 1) & 7)) * 4
-      int prow[PT], py[PT];
+  for (;;) {
+    const int m0 = (tile / panels) * BM;
+    const int mlast = min(m0 + BM, a.M) - 1;
+    // per-lane pixel rows of this wave's tiles
+    int ibase[PT];  // slab index of the pixel at the centre tap
+    int opix[PT];   // padded-flat index in the output / residual tensor (same geometry as the input)
+    bool ok[PT];
 #pragma unroll
-      for (int i = 0; i < PT; ++i) {
-        const int idx = ibase[i] + tapoff;
-        prow[i] = sb * SLAB + idx * 32;
-        py[i] = (hh ^ ((idx >> 1) & 7)) << 2;
-      }
-      const float* pW = smem + 2 * SLAB + wb * WT + (wn * CT * 32 + l31) * 32;
+    for (int i = 0; i < PT; ++i) {
+      const int m = m0 + (wm * PT + i) * 32 + l31;
+      ok[i] = m < a.M;
+      opix[i] = padded_index(ok[i] ? m : mlast, HW, W);
+      ibase[i] = opix[i] - lo;
+    }
+    const int tnext = tile + (int)gridDim.x;
+    const bool more = tnext < ntiles;
+    int nlo = 0, nnp = 0;
+    if (more) TILE_GEOMETRY(tnext / panels, nlo, nnp)
+
+    f32x16 acc[PT][CT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int kt = 0;
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int sb = ch & 1;
+      for (int tap = 0; tap < 9; ++tap, ++kt) {
+        const int wb = kt & 1;
+        // next K-step's weights, and this wave's share of the next slab (next chunk, or chunk 0 of the
+        // workgroup's next tile)
+        if (tap < 8) {
+          WEIGHT_TILE(ch, tap + 1, wb ^ 1)
+        } else if (ch + 1 < NCH) {
+          WEIGHT_TILE(ch + 1, 0, wb ^ 1)
+        } else if (more) {
+          WEIGHT_TILE(0, 0, wb ^ 1)
+        }
+        if (ch + 1 < NCH) {
+          SLAB_PIECE(lo, npieces, ch + 1, sb ^ 1, tap)
+        } else if (more) {
+          SLAB_PIECE(nlo, nnp, 0, 0, tap)
+        }
+
+        const int r = tap / 3, s = tap - r * 3;
+        const int tapoff = (r - 1) * Wp + (s - 1);
+        // pixel fragment addresses: slab row idx = ibase + tapoff, slot (2 kg + hh) ^ ((idx >> 1) & 7),
+        // i.e. float offset (8 kg) ^ py with py = (hh ^ ((idx >> 1) & 7)) * 4
+        int prow[PT], py[PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+          const int idx = ibase[i] + tapoff;
+          prow[i] = sb * SLAB + idx * 32;
+          py[i] = (hh ^ ((idx >> 1) & 7)) << 2;
+        }
+        const float* pW = smem + 2 * SLAB + wb * WT + (wn * CT * 32 + l31) * 32;
 #define PXF(G) *reinterpret_cast<const float4*>(smem + prow[i] + ((8 * (G)) ^ py[i]))
 #define WTF(G) *reinterpret_cast<const float4*>(pW + j * 1024 + ((G) == 0 ? fo0 : (G) == 1 ? fo1 : (G) == 2 ? fo2 : fo3))
-      if (MM == MM_F16X3) {
-        SE3TN_MMA_SPLIT(PT, CT, PXF, WTF)
-      } else {
-        SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
-        SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
-        SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
-        SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
-      }
+        if (MM == MM_F16X3) {
+          SE3TN_MMA_SPLIT(PT, CT, PXF, WTF)
+        } else {
+          SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
+          SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
+          SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
+          SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
+        }
 #undef PXF
 #undef WTF
-      if (kt + 1 < NCH * 9) wait_dma_and_barrier();
+        if (kt + 1 < NCH * 9 || more) wait_dma_and_barrier();
+      }
     }
+    store_tiles<PT, CT, EPI, MM, OUTF, RESF>(a, g, acc, opix, ok, n0 + wn * CT * 32, hh);
+    if (!more) break;
+    tile = tnext;
+    lo = nlo;
+    npieces = nnp;
   }
 #undef SLAB_PIECE
 #undef WEIGHT_TILE
-  store_tiles<PT, CT, EPI, MM, OUTF, RESF>(a, g, acc, opix, ok, n0 + wn * CT * 32, hh);
+#undef TILE_GEOMETRY
 }
 
 // =================================================================================================
@@ -500,7 +536,10 @@ static hipError_t launch_slab(const ConvArgs& a, hipStream_t st) {
   hipError_t e = set_lds(kern, lds, attr);
   if (e != hipSuccess) return e;
   const int tiles_m = (a.M + BM - 1) / BM;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * a.tiles_n * a.groups), dim3(512), lds, st, a);
+  // one workgroup per CU (LDS-bound); with more tiles than CUs the workgroups are persistent
+  const int ntiles = tiles_m * a.tiles_n * a.groups;
+  const int grid = (SE3TN_PERSISTENT_SLAB && ntiles > 256) ? 256 : ntiles;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
   return hipGetLastError();
 }
 
