@@ -31,8 +31,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step")
     ap.add_argument("--stage", default="full", choices=["full", "net"],
                     help="full = preprocess + network + pose update (default); net = network + pose on "
@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--winograd", type=int, default=None, metavar="MIN_BATCH",
                     help="se3tn_set_winograd threshold (0 = direct kernels only; default: the library's)")
     ap.add_argument("--winograd-tile", type=int, default=0, choices=[0, 2, 4], help="F(tile x tile,3x3); 0 = library default")
+    ap.add_argument("--gather-every-step", action="store_true",
+                    help="N > 1: all-gather the poses after every step (overlapped with the next step) instead of once "
+                         "at the end of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch time breakdown to stderr")
     args = ap.parse_args()
@@ -96,27 +99,48 @@ def main():
     poses[:, 0, 3] = rng.uniform(-0.15, 0.15, nb); poses[:, 1, 3] = rng.uniform(-0.1, 0.1, nb)
     poses[:, 2, 3] = rng.uniform(0.6, 1.0, nb)
     K = np.array([[1066.778, 0, 312.9869], [0, 1067.487, 241.3109], [0, 0, 1]])
-    cropsA, cropsB = [], []
-    for i in range(nb):
-        bb = se3.compute_bbox(poses[i], K, 250.0)
-        z = float(poses[i, 2, 3]) * 1000
-        cropsA.append(dict(rgb=rend_rgb[i], depth=rend_d[i], window=(0, 0, 176, 176), z_offset_mm=z, stats=0))
-        cropsB.append(dict(rgb=frames_rgb[i], depth=frames_d[i], window=se3.crop_window(bb), z_offset_mm=z, stats=1))
+    windowsA = np.tile(np.array([0, 0, 176, 176]), (nb, 1))
+    windowsB = np.array([se3.crop_window(se3.compute_bbox(poses[i], K, 250.0)) for i in range(nb)])
+    z_mm = poses[:, 2, 3] * 1000.0
+
+    def make_crops():   # per step, like a tracker would: 2 x nb descriptors, vectorised (no per-crop Python)
+        return (se3.pack_crops(rend_rgb, rend_d, windowsA, z_mm, 0), se3.pack_crops(frames_rgb, frames_d, windowsB, z_mm, 1))
+    cropsA, cropsB = make_crops()
     poseA = torch.from_numpy(poses.reshape(nb, 16)).to(dev)
     poseB = torch.empty_like(poseA)
+    poseB_alt = torch.empty_like(poseA)   # N > 1: poses of step k are all-gathered while step k+1 computes
     trans = torch.empty((nb, 3), device=dev); rot = torch.empty((nb, 3), device=dev)
     inA, inB = eng.input_buffer_ptr(0), eng.input_buffer_ptr(1)
     if args.stage == "net":
         eng.preprocess(cropsA, inA); eng.preprocess(cropsB, inB)
 
+    pending = []   # [(gathered poses, work)] of the previous step
+
     def step():
         if args.stage == "full":
-            eng.preprocess(cropsA, inA)
-            eng.preprocess(cropsB, inB)
-        eng.infer(inA, inB, nb, se3.NHWC, trans, rot, poseA, poseB)
-        if use_dist:
+            cA, cB = make_crops()
+            eng.preprocess(cA, inA)
+            eng.preprocess(cB, inB)
+        if not (use_dist and args.gather_every_step):
+            eng.infer(inA, inB, nb, se3.NHWC, trans, rot, poseA, poseB)
+            return poseB
+        # C2, overlapped: step k writes pose buffer k % 2; its all-gather runs on the RCCL stream while
+        # step k+1 computes into the other buffer; the gather of step k-1 is retired first
+        buf = poseB if len(pending) == 0 or pending[-1][2] is poseB_alt else poseB_alt
+        eng.infer(inA, inB, nb, se3.NHWC, trans, rot, poseA, buf)
+        while pending:
+            pending.pop(0)[1].wait()
+        out, work = dist_mod.gather_poses_async(buf)
+        pending.append((out, work, buf))
+        return out
+
+    def drain():
+        # the path shards by pairs and has no exchange step: by default the ranks' poses are
+        # collected ONCE, here, inside the timed region
+        if use_dist and not args.gather_every_step:
             return dist_mod.gather_poses(poseB)      # C2
-        return poseB
+        while pending:
+            pending.pop(0)[1].wait()
 
     def timed_loop(steps):
         torch.cuda.synchronize()
@@ -126,6 +150,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -212,7 +237,8 @@ def main():
             "config": {"workload": "configs[1]: batch=%d synthetic 176x176 RGB-D pairs per GPU, random-init Se3TrackNet "
                                    "(reference state_dict surface), stage=%s" % (nb, args.stage),
                        "pairs_per_gpu": nb, "global_batch": world * nb, "stage": args.stage,
-                       "parallelism": "frame-sharded x%d, RCCL weight broadcast + pose all-gather" % world},
+                       "parallelism": "frame-sharded x%d, RCCL weight broadcast at start-up, pose all-gather %s" %
+                                      (world, "every step (overlapped)" if args.gather_every_step else "once per timed region")},
             "tflops_total": round(value * FLOP_PER_PAIR / 1e12, 2),
             "roofline": {"bound": "mfma",
                          "kernel": "3x3 conv family, 10 convs/step on exact-f32 v_mfma_f32_32x32x2_f32: direct implicit GEMM "

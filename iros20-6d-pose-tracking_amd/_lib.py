@@ -27,6 +27,13 @@ class Crop(C.Structure):
                 ("z_offset_mm", C.c_double), ("stats", C.c_int32), ("_pad", C.c_int32)]
 
 
+# the same record as a numpy dtype, for building many descriptors without a Python loop
+import numpy as _np
+CROP_DTYPE = _np.dtype([("rgb", "<u8"), ("depth", "<u8"), ("H", "<i4"), ("W", "<i4"), ("left", "<i4"), ("top", "<i4"),
+                        ("right", "<i4"), ("bottom", "<i4"), ("z_offset_mm", "<f8"), ("stats", "<i4"), ("_pad", "<i4")])
+assert CROP_DTYPE.itemsize == C.sizeof(Crop)
+
+
 _SIGS = {
     "se3tn_version": (C.c_char_p, []),
     "se3tn_last_error": (C.c_char_p, []),

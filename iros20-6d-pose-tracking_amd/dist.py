@@ -43,3 +43,15 @@ def gather_poses(local_poses, group=None):
                       dtype=local_poses.dtype, device=local_poses.device)
     dist.all_gather_into_tensor(out, local_poses.contiguous(), group=group)
     return out
+
+
+def gather_poses_async(local_poses, group=None):
+    """C2 without putting the collective on the compute stream's critical path: returns (out, work);
+    the all-gather runs on the backend's own stream (after everything already queued on the current
+    stream), the caller keeps computing into a DIFFERENT pose buffer and calls work.wait() before it
+    reads `out` or reuses `local_poses`."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world * local_poses.shape[0],) + tuple(local_poses.shape[1:]),
+                      dtype=local_poses.dtype, device=local_poses.device)
+    work = dist.all_gather_into_tensor(out, local_poses.contiguous(), group=group, async_op=True)
+    return out, work

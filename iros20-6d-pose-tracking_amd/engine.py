@@ -6,11 +6,30 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import NCHW, NHWC, RES, Crop, Se3tnError, check
+from ._lib import CROP_DTYPE, NCHW, NHWC, RES, Crop, Se3tnError, check
 
 
 def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pack_crops(rgb, depth, windows, z_offset_mm, stats):
+    """Vectorised se3tn_crop descriptors for a batch of frames that live in ONE tensor each:
+    rgb cuda u8 [n,H,W,3], depth cuda 2-byte [n,H,W], windows int [n,4] (left,top,right,bottom),
+    z_offset_mm float [n], stats 0|1.  Returns a numpy record array accepted by Engine.preprocess."""
+    assert rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.is_contiguous() and rgb.dim() == 4 and rgb.shape[3] == 3
+    assert depth.is_cuda and depth.element_size() == 2 and depth.is_contiguous() and depth.shape == rgb.shape[:3]
+    n, H, W = int(rgb.shape[0]), int(rgb.shape[1]), int(rgb.shape[2])
+    rec = np.zeros(n, dtype=CROP_DTYPE)
+    idx = np.arange(n, dtype=np.uint64)
+    rec["rgb"] = np.uint64(rgb.data_ptr()) + idx * np.uint64(H * W * 3)
+    rec["depth"] = np.uint64(depth.data_ptr()) + idx * np.uint64(H * W * 2)
+    rec["H"] = H; rec["W"] = W
+    win = np.asarray(windows, dtype=np.int64).reshape(n, 4)
+    rec["left"], rec["top"], rec["right"], rec["bottom"] = win[:, 0], win[:, 1], win[:, 2], win[:, 3]
+    rec["z_offset_mm"] = np.asarray(z_offset_mm, dtype=np.float64)
+    rec["stats"] = int(stats)
+    return rec
 
 
 class Engine:
@@ -118,19 +137,25 @@ class Engine:
 
     def preprocess(self, crops, out):
         """crops: list of dict(rgb=cuda u8 [H,W,3], depth=cuda u16-as-int16/uint16 [H,W],
-        window=(left,top,right,bottom), z_offset_mm=float, stats=0|1).
+        window=(left,top,right,bottom), z_offset_mm=float, stats=0|1), or the packed descriptor array
+        returned by pack_crops() (no per-crop Python work).
         out: cuda float32 tensor [n,176,176,4] or a raw device pointer (int)."""
-        n = len(crops)
-        arr = (Crop * n)()
-        for i, c in enumerate(crops):
-            rgb, depth = c["rgb"], c["depth"]
-            assert rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.is_contiguous() and rgb.shape[2] == 3
-            assert depth.is_cuda and depth.element_size() == 2 and depth.is_contiguous()
-            arr[i].rgb = rgb.data_ptr(); arr[i].depth = depth.data_ptr()
-            arr[i].H, arr[i].W = int(rgb.shape[0]), int(rgb.shape[1])
-            arr[i].left, arr[i].top, arr[i].right, arr[i].bottom = [int(v) for v in c["window"]]
-            arr[i].z_offset_mm = float(c["z_offset_mm"])
-            arr[i].stats = int(c["stats"])
+        if isinstance(crops, np.ndarray):
+            assert crops.dtype == CROP_DTYPE and crops.flags.c_contiguous
+            n = crops.shape[0]
+            arr = crops.ctypes.data_as(C.POINTER(Crop))
+        else:
+            n = len(crops)
+            arr = (Crop * n)()
+            for i, c in enumerate(crops):
+                rgb, depth = c["rgb"], c["depth"]
+                assert rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.is_contiguous() and rgb.shape[2] == 3
+                assert depth.is_cuda and depth.element_size() == 2 and depth.is_contiguous()
+                arr[i].rgb = rgb.data_ptr(); arr[i].depth = depth.data_ptr()
+                arr[i].H, arr[i].W = int(rgb.shape[0]), int(rgb.shape[1])
+                arr[i].left, arr[i].top, arr[i].right, arr[i].bottom = [int(v) for v in c["window"]]
+                arr[i].z_offset_mm = float(c["z_offset_mm"])
+                arr[i].stats = int(c["stats"])
         ptr = out.data_ptr() if torch.is_tensor(out) else int(out)
         check(self.lib.se3tn_preprocess(self._h, arr, n, C.c_void_p(ptr), _stream_ptr()), "se3tn_preprocess")
 

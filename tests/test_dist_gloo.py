@@ -38,6 +38,17 @@ def _worker(rank, world, port, q):
         allp = D.gather_poses(local)
         assert allp.shape == (4 * world, 16)
         assert all(float(allp[4 * r, 0]) == r for r in range(world))
+        # the overlapped form used by bench.py at N > 1: double-buffered local poses, lagged wait
+        bufs = [torch.empty((4, 16), dtype=torch.float64) for _ in range(2)]
+        prev = None
+        for k in range(4):
+            bufs[k % 2].fill_(100.0 * k + rank)
+            if prev is not None:
+                prev[1].wait()
+                assert all(float(prev[0][4 * r, 3]) == 100.0 * (k - 1) + r for r in range(world))
+            prev = D.gather_poses_async(bufs[k % 2])
+        prev[1].wait()
+        assert all(float(prev[0][4 * r, 3]) == 300.0 + r for r in range(world))
         q.put((rank, "ok"))
     except Exception as e:  # noqa
         q.put((rank, repr(e)))

@@ -105,6 +105,28 @@ def test_more_crops_than_one_launch_holds(se3):
         assert (out[i].permute(2, 0, 1).cpu().numpy() == want).all(), i
 
 
+def test_pack_crops_descriptors_equal_the_dict_path(se3):
+    """The vectorised descriptor builder (one tensor of frames, numpy record array) drives
+    se3tn_preprocess to the same bits as per-crop dicts."""
+    rng = np.random.default_rng(4)
+    n = 30
+    rgb = torch.from_numpy(rng.integers(0, 256, (n, 120, 160, 3), dtype=np.uint8)).cuda()
+    depth = torch.from_numpy(rng.integers(300, 1500, (n, 120, 160)).astype(np.uint16).view(np.int16)).cuda()
+    eng = se3.Engine(0, 32)
+    mean, std = Fx.mean_std(0)
+    eng.set_normalization(mean, std)
+    wins = np.array([(i - 10, 5 - i, i + 100, 110 - i) for i in range(n)])
+    z = 500.0 + np.arange(n)
+    a = torch.empty((n, 176, 176, 4), device="cuda"); b = torch.empty_like(a)
+    eng.preprocess([dict(rgb=rgb[i], depth=depth[i], window=tuple(wins[i]), z_offset_mm=z[i], stats=1) for i in range(n)], a)
+    rec = se3.pack_crops(rgb, depth, wins, z, 1)
+    assert rec.dtype.itemsize == 56 and rec.shape == (n,)
+    eng.preprocess(rec, b)
+    assert torch.equal(a, b)
+    want = _oracle_crop(rgb[7].cpu().numpy(), depth[7].cpu().numpy().view(np.uint16), tuple(wins[7]), z[7], mean, std, 1)
+    assert (b[7].permute(2, 0, 1).cpu().numpy() == want).all()
+
+
 def test_external_nhwc_equals_nchw_and_internal_buffers(se3):
     sd = O.make_state_dict(0)
     eng = se3.Engine(0, 4)
