@@ -350,7 +350,12 @@ def test_f16x3_numerics_under_awkward_scales(se3, seed):
     m.load_state_dict(sd); m.cuda(0)
     eng = m.engine
     m(A.cuda(), B.cuda(), return_feature=False)
-    l32 = eng.logits(n).clone()
+    l32 = eng.logits(n).clone()              # float32, default algorithms: n = 32 -> Winograd F(4x4) blocks
+    eng.set_winograd(0)
+    m(A.cuda(), B.cuda(), return_feature=False)
+    l32d = eng.logits(n).clone()             # float32, direct kernels only
+    eng.set_winograd(6, 4)
+    assert not torch.equal(l32, l32d)
     eng.set_precision(se3._lib.PREC_F16X3)
     m(A.cuda(), B.cuda(), return_feature=False)
     l16 = eng.logits(n).clone()
@@ -359,7 +364,10 @@ def test_f16x3_numerics_under_awkward_scales(se3, seed):
     want = torch.cat([ref["trans_logit"], ref["rot_logit"]], 1)
     scale = float(want.abs().max()) + 1.0
     e32 = float((l32[:2].cpu() - want).abs().max()) / scale
+    e32d = float((l32d[:2].cpu() - want).abs().max()) / scale
     e16 = float((l16[:2].cpu() - want).abs().max()) / scale
-    d = float((l16 - l32).abs().max()) / scale
-    print("seed %d: rel err f32 %.2e  f16x3 %.2e  |f16x3 - f32| %.2e (logit scale %.2f)" % (seed, e32, e16, d, scale))
-    assert e32 < 2e-5 and e16 < 2e-5 and d < 2e-5
+    d = float((l16 - l32d).abs().max()) / scale
+    dw = float((l32 - l32d).abs().max()) / scale
+    print("seed %d: rel err f32 direct %.2e  f32 Winograd %.2e  f16x3 %.2e  |f16x3 - direct| %.2e  |Winograd - direct| %.2e "
+          "(logit scale %.2f)" % (seed, e32d, e32, e16, d, dw, scale))
+    assert e32 < 2e-5 and e32d < 2e-5 and e16 < 2e-5 and d < 2e-5 and dw < 2e-5
