@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
   constexpr int BM = WM * PT * 32, BN = WN * CT * 32;
   constexpr int NCH = CIN / 32;
   constexpr int BUF = (BM + BN) * 32;
-  static_assert(WM * WN == 4 && BN == 128, "4 waves, 128 couts");
+  static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -277,10 +277,8 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
     const unsigned lb_ = lds0 + (unsigned)(((BUFI) * BUF + wid * 256) * 4);                          \
     _Pragma("unroll") for (int j_ = 0; j_ < BM / 32; ++j_) glds16<0>(pb_, pvoff[j_], lb_ + j_ * 4096); \
     const float* tb_ = Ub + (size_t)(CH) * a.nf * a.Cout * 32;                                       \
-    glds16<0>(tb_, wvoff, lb_ + BM * 128);                                                           \
-    glds16<0>(tb_ + 1024, wvoff, lb_ + BM * 128 + 4096);                                             \
-    glds16<0>(tb_ + 2048, wvoff, lb_ + BM * 128 + 8192);                                             \
-    glds16<0>(tb_ + 3072, wvoff, lb_ + BM * 128 + 12288);                                            \
+    _Pragma("unroll") for (int j_ = 0; j_ < BN / 32; ++j_)                                           \
+        glds16<0>(tb_ + 1024 * j_, wvoff, lb_ + BM * 128 + j_ * 4096);                               \
   }
 
   const int X = (l31 >> 1) & 7;
@@ -348,15 +346,15 @@ template <int CIN, int WM, int WN, int PT, int CT>
 static hipError_t launch_gemm(const WinoArgs& a, hipStream_t st) {
   static bool attr = false;
   auto kern = wino_gemm_kernel<CIN, WM, WN, PT, CT>;
-  constexpr int BM = WM * PT * 32;
-  const size_t lds = 2 * (BM + 128) * 32 * sizeof(float);
+  constexpr int BM = WM * PT * 32, BN = WN * CT * 32;
+  const size_t lds = 2 * (BM + BN) * 32 * sizeof(float);
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  const int grid = (a.Cout / 128) * ((a.T + BM - 1) / BM) * a.groups * a.nf;
+  const int grid = (a.Cout / BN) * ((a.T + BM - 1) / BM) * a.groups * a.nf;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
