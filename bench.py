@@ -261,7 +261,7 @@ def main():
             out["alt_precision"] = other
         if direct is not None:
             out["alt_algorithm"] = direct
-        tr, src = pmc_traffic(nb)
+        tr, src = pmc_traffic(nb, wino_on)
         if tr is not None:
             out["roofline"]["traffic"] = int(tr)
             out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per step)" % src
@@ -275,7 +275,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(nb):
+def pmc_traffic(nb, wino_on):
     """HBM bytes per step of the conv3x3 family from the newest committed rocprofv3 PMC summary
     (profiles/*_pmc.json: FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, KB, separate passes of
     this same command at batch 64).  Not collected live (PMC needs rocprofv3 around the process)."""
@@ -289,6 +289,8 @@ def pmc_traffic(nb):
     wino_calls = {"wino_input_kernel": 4, "wino_gemm_kernel": 2, "wino_output_kernel": 2}   # per instantiation
     for k, v in d["fetch"].items():
         if k.startswith("wino_") and k.split("<")[0] in wino_calls:
+            if not wino_on:
+                continue
             total += wino_calls[k.split("<")[0]] * (2.0 * v["FETCH_SIZE"] + d["write"][k]["WRITE_SIZE"]) * 1024.0
             continue
         if not k.startswith("conv3x3") or "<" not in k:
@@ -297,6 +299,8 @@ def pmc_traffic(nb):
         mm = targs[7] if k.startswith("conv3x3_slab") else targs[2]  # arithmetic mode template argument
         if mm != "0":
             continue  # the float32 instantiations only (the summary also holds the f16x3 ones)
+        if wino_on and k.startswith("conv3x3_slab") and targs[0] in ("256", "512"):
+            continue  # these layers ran as Winograd in the headline leg (the direct kernels are the alt_algorithm leg)
         calls = 2 if targs[0] == "64" else 1
         total += calls * (2.0 * v["FETCH_SIZE"] + d["write"][k]["WRITE_SIZE"]) * 1024.0
     return total, os.path.basename(files[-1])
