@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--gather-every-step", action="store_true",
                     help="N > 1: all-gather the poses after every step (overlapped with the next step) instead of once "
                          "at the end of the timed region")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="PCIe-inclusive variant (never the headline): every step's camera frames start in pinned host "
+                         "memory and are uploaded on a copy stream, double-buffered against the previous step's compute")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch time breakdown to stderr")
     args = ap.parse_args()
@@ -103,8 +106,28 @@ def main():
     windowsB = np.array([se3.crop_window(se3.compute_bbox(poses[i], K, 250.0)) for i in range(nb)])
     z_mm = poses[:, 2, 3] * 1000.0
 
-    def make_crops():   # per step, like a tracker would: 2 x nb descriptors, vectorised (no per-crop Python)
-        return (se3.pack_crops(rend_rgb, rend_d, windowsA, z_mm, 0), se3.pack_crops(frames_rgb, frames_d, windowsB, z_mm, 1))
+    # --host-frames: two device frame sets, filled alternately from pinned host memory by a copy stream
+    frame_sets = [(frames_rgb, frames_d)]
+    if args.host_frames:
+        frame_sets.append((torch.empty_like(frames_rgb), torch.empty_like(frames_d)))
+        host_rgb, host_d = frames_rgb.cpu().pin_memory(), frames_d.cpu().pin_memory()
+        copy_stream = torch.cuda.Stream(device=dev)
+        uploaded = [torch.cuda.Event(), torch.cuda.Event()]   # set k's upload finished
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]   # set k's last reader (preprocess) finished
+        for e in consumed:
+            e.record()
+    step_no = [0]
+
+    def upload(k):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[k])
+            frame_sets[k][0].copy_(host_rgb, non_blocking=True)
+            frame_sets[k][1].copy_(host_d, non_blocking=True)
+            uploaded[k].record(copy_stream)
+
+    def make_crops(k=0):   # per step, like a tracker would: 2 x nb descriptors, vectorised (no per-crop Python)
+        return (se3.pack_crops(rend_rgb, rend_d, windowsA, z_mm, 0),
+                se3.pack_crops(frame_sets[k][0], frame_sets[k][1], windowsB, z_mm, 1))
     cropsA, cropsB = make_crops()
     poseA = torch.from_numpy(poses.reshape(nb, 16)).to(dev)
     poseB = torch.empty_like(poseA)
@@ -118,9 +141,19 @@ def main():
 
     def step():
         if args.stage == "full":
-            cA, cB = make_crops()
+            k = 0
+            if args.host_frames:
+                k = step_no[0] & 1
+                if step_no[0] == 0:
+                    upload(0)
+                upload(k ^ 1)                                   # next step's frames, under this step's compute
+                torch.cuda.current_stream().wait_event(uploaded[k])
+                step_no[0] += 1
+            cA, cB = make_crops(k)
             eng.preprocess(cA, inA)
             eng.preprocess(cB, inB)
+            if args.host_frames:
+                consumed[k].record()
         if not (use_dist and args.gather_every_step):
             eng.infer(inA, inB, nb, se3.NHWC, trans, rot, poseA, poseB)
             return poseB
@@ -237,6 +270,7 @@ def main():
             "config": {"workload": "configs[1]: batch=%d synthetic 176x176 RGB-D pairs per GPU, random-init Se3TrackNet "
                                    "(reference state_dict surface), stage=%s" % (nb, args.stage),
                        "pairs_per_gpu": nb, "global_batch": world * nb, "stage": args.stage,
+                       "frames": "pinned host memory, uploaded per step (PCIe-inclusive)" if args.host_frames else "resident in HBM",
                        "parallelism": "frame-sharded x%d, RCCL weight broadcast at start-up, pose all-gather %s" %
                                       (world, "every step (overlapped)" if args.gather_every_step else "once per timed region")},
             "tflops_total": round(value * FLOP_PER_PAIR / 1e12, 2),
