@@ -127,3 +127,73 @@ def eval_one_class(res_dir, ycb_dir, class_id):
     adi_errs = np.sort(np.array(adi_errs)); add_errs = np.sort(np.array(add_errs))
     return {"add_auc": metrics.VOCap(add_errs) * 100, "adi_auc": metrics.VOCap(adi_errs) * 100,
             "adi_errs": adi_errs, "add_errs": add_errs, "n": len(adi_errs)}
+
+
+YCBINEOAT_OBJECTS = ("cracker", "bleach", "sugar", "tomato", "mustard")   # eval_ycbineoat.py:48
+
+
+def predict_sequence_ycbineoat(tracker, data_dir, out_dir, max_frames=None):
+    """predict.py:578-626 `predictSequenceYcbInEOAT` without the GUI: <data_dir>/rgb/*.png,
+    depth_filled/*.png (uint16 mm), annotated_poses/*.txt; the track starts from the first annotated
+    pose and -- unlike the YCB-Video driver -- frame 0 itself is tracked too; every pose is written as
+    <out_dir>/%07d.txt.  The reference builds this Tracker with rot_normalizer = 30 deg (:586); pass a
+    tracker constructed that way.  Returns {"poses": [n,4,4], "hz": ...}."""
+    rgb_files = sorted(glob.glob(os.path.join(data_dir, "rgb", "*.png")))
+    depth_files = sorted(glob.glob(os.path.join(data_dir, "depth_filled", "*.png")))
+    gt_files = sorted(glob.glob(os.path.join(data_dir, "annotated_poses", "*.txt")))
+    assert len(rgb_files) == len(depth_files) > 0 and len(gt_files) > 0, "incomplete YCBInEOAT directory"
+    n = len(rgb_files) if max_frames is None else min(len(rgb_files), max_frames)
+    prev_pose = np.loadtxt(gt_files[0]).copy()
+    os.makedirs(out_dir, exist_ok=True)
+    poses, t_track = [], 0.0
+    for i in range(n):
+        rgb = read_rgb(rgb_files[i])
+        depth = read_depth_mm(depth_files[i])
+        t0 = time.perf_counter()
+        cur_pose = tracker.on_track(prev_pose.copy(), rgb, depth, gt_A_in_cam=np.eye(4), gt_B_in_cam=np.eye(4))
+        t_track += time.perf_counter() - t0
+        prev_pose = cur_pose.copy()
+        np.savetxt(os.path.join(out_dir, "%07d.txt" % i), cur_pose)
+        poses.append(cur_pose)
+    return {"poses": np.array(poses), "frames": n, "hz": n / t_track if t_track > 0 else float("nan")}
+
+
+def eval_ycbineoat(res_dir, data_dir, ycb_dir, objects=YCBINEOAT_OBJECTS):
+    """eval_ycbineoat.py:45-109 `eval_all`: every folder of res_dir (one per video, named after it) is
+    matched to an object by substring, its %07d.txt poses are compared one-to-one with
+    <data_dir>/<folder>/annotated_poses/*.txt, the model is the CADmodels/*/points.xyz whose path
+    contains the object name.  Returns per-object and overall ADD / ADD-S AUC (x100)."""
+    models = {}
+    for t in sorted(glob.glob(os.path.join(ycb_dir, "CADmodels", "*", "points.xyz"))):
+        for obj in objects:
+            if obj in t:
+                models[obj] = np.loadtxt(t).reshape(-1, 3)
+    class_res = {obj: {"add": [], "add-s": []} for obj in objects}
+    for folder in sorted(os.listdir(res_dir)):
+        if ".tar.gz" in folder or not os.path.isdir(os.path.join(res_dir, folder)):
+            continue
+        obj = next((o for o in objects if o in folder), None)
+        assert obj is not None, "result folder %s names no known object" % folder
+        pred_files = sorted(glob.glob(os.path.join(res_dir, folder, "*.txt")))
+        gt_files = sorted(glob.glob(os.path.join(data_dir, folder, "annotated_poses", "*.txt")))
+        assert len(pred_files) == len(gt_files), "#pred_files:%d, #gt_files:%d" % (len(pred_files), len(gt_files))
+        for pf, gf in zip(pred_files, gt_files):
+            pred, gt = np.loadtxt(pf), np.loadtxt(gf)
+            class_res[obj]["add"].append(metrics.add(pred, gt, models[obj]))
+            class_res[obj]["add-s"].append(metrics.adi(pred, gt, models[obj]))
+
+    def auc(errs):
+        try:
+            return metrics.VOCap(np.array(errs)) * 100
+        except IndexError:   # nothing below 0.1 m (the reference's VOCap raises); empty lists too
+            return 0.0
+    out = {"per_object": {}, "n": 0}
+    adds, adis = [], []
+    for obj in objects:
+        a, s_ = class_res[obj]["add"], class_res[obj]["add-s"]
+        if not a:
+            continue
+        out["per_object"][obj] = {"add_auc": auc(a), "adi_auc": auc(s_), "n": len(a)}
+        adds += a; adis += s_
+    out.update(add_auc=auc(adds), adi_auc=auc(adis), n=len(adis))
+    return out

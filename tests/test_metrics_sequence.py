@@ -125,3 +125,39 @@ def test_get_results_and_eval_one_class_file_formats(se3, tmp_path):
     assert np.allclose(np.loadtxt(out + "seq48/0000000.txt"), P)     # GT initialisation
     res = se3.sequence.eval_one_class(out, str(ycb), 2)
     assert res["n"] == 3 and 0 <= res["adi_auc"] <= 100 and res["adi_errs"][0] == 0.0   # frame 1 == GT
+
+
+@pytest.mark.gpu
+def test_ycbineoat_driver_and_eval_file_formats(se3, tmp_path):
+    """predictSequenceYcbInEOAT / eval_ycbineoat.py layouts on a synthetic tree: rgb/ depth_filled/
+    annotated_poses/ in, %07d.txt out (frame 0 tracked too, rot_normalizer 30 deg), results folder
+    matched to its object by name."""
+    data = tmp_path / "eoat"
+    vid = "mustard0"
+    for d in ("rgb", "depth_filled", "annotated_poses"):
+        os.makedirs(data / vid / d)
+    P = Fx.pose(3)
+    n = 4
+    for i in range(n):
+        rgb, depth = Fx.synthetic_frame(200 + i)
+        Image.fromarray(rgb).save(data / vid / "rgb" / ("%07d.png" % i))
+        Image.fromarray(depth).save(data / vid / "depth_filled" / ("%07d.png" % i))
+        np.savetxt(data / vid / "annotated_poses" / ("%07d.txt" % i), P)
+    ycb = tmp_path / "ycb"
+    for c in ("003_cracker_box", "006_mustard_bottle"):
+        os.makedirs(ycb / "CADmodels" / c)
+        np.savetxt(ycb / "CADmodels" / c / "points.xyz", np.random.default_rng(2).uniform(-0.04, 0.04, (150, 3)))
+    sd = O.make_state_dict(0, head_gain=0.0005)
+    mean, std = Fx.mean_std(0)
+    trk = se3.Tracker(Fx.DATASET_INFO, mean, std, {"state_dict": sd}, renderer=_Render(),
+                      trans_normalizer=0.03, rot_normalizer=30 * np.pi / 180)
+    res_dir = tmp_path / "res"
+    out = se3.sequence.predict_sequence_ycbineoat(trk, str(data / vid), str(res_dir / vid))
+    assert out["poses"].shape == (n, 4, 4) and sorted(os.listdir(res_dir / vid)) == ["%07d.txt" % i for i in range(n)]
+    # frame 0 is a tracked frame (not the GT copy), with the 30-degree rotation normaliser
+    rgb0, depth0 = Fx.synthetic_frame(200)
+    want, _ = O.on_track(sd, P, rgb0, depth0, *Fx.synthetic_render(11, P[2, 3]), Fx.K_YCB, trk.object_width, mean, std,
+                         rot_normalizer=30 * np.pi / 180)
+    assert np.abs(out["poses"][0] - want).max() < 1e-5 and np.abs(out["poses"][0] - P).max() > 0
+    ev = se3.sequence.eval_ycbineoat(str(res_dir), str(data), str(ycb))
+    assert list(ev["per_object"]) == ["mustard"] and ev["n"] == n and 0 <= ev["adi_auc"] <= 100
