@@ -237,6 +237,38 @@ def test_hipgraph_replay_matches_eager(se3):
     assert any(g for g in [graph.engine]) and graph._stream is not None
 
 
+def test_hipgraph_replay_of_the_winograd_path(se3):
+    """n = 8 >= SE3TN_WINOGRAD_DEFAULT_MIN_BATCH: the captured graph contains the Winograd transform and
+    GEMM kernels; replays are bit-identical to eager and follow new input data in the same buffers."""
+    sd = O.make_state_dict(0)
+    n = 8
+    eng = se3.Engine(0, n)
+    eng.load_state_dict(sd)
+    assert eng.get_winograd()[0] <= n
+    tr, ro = torch.empty((n, 3), device="cuda"), torch.empty((n, 3), device="cuda")
+    A, B = Fx.net_inputs(21, n)
+    Ac, Bc = A.cuda(), B.cuda()
+    eng.infer(Ac, Bc, n, se3.NCHW, tr, ro)
+    want = (tr.clone(), ro.clone(), eng.logits(n).clone())
+    st = torch.cuda.Stream()
+    eng.enable_graphs(True)
+    with torch.cuda.stream(st):
+        for it in range(4):          # eager, capture, replay, replay
+            tr.zero_(); ro.zero_()
+            eng.infer(Ac, Bc, n, se3.NCHW, tr, ro)
+            st.synchronize()
+            assert torch.equal(tr, want[0]) and torch.equal(ro, want[1]) and torch.equal(eng.logits(n), want[2]), it
+        A2, B2 = Fx.net_inputs(22, n)
+        Ac.copy_(A2.cuda()); Bc.copy_(B2.cuda())     # same pointers, new content
+        eng.infer(Ac, Bc, n, se3.NCHW, tr, ro)
+        st.synchronize()
+        got = tr.clone()
+    eng.enable_graphs(False)
+    eng.infer(Ac, Bc, n, se3.NCHW, tr, ro)
+    torch.cuda.synchronize()
+    assert torch.equal(got, tr) and not torch.equal(got, want[0])
+
+
 def test_large_batch_192_matches_single_pairs(se3):
     """Maximum-size style check: a 192-pair call (3x BASELINE's batch; offsets beyond 2^31 bytes in the
     stem buffer) agrees pair-by-pair with single-pair calls, in both arithmetic modes."""
