@@ -233,14 +233,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_slab_kernel(const ConvArgs a) 
         if (MM == MM_F16X3) {
           SE3TN_MMA_SPLIT(PT, CT, PXF, WTF)
         } else {
-#ifdef SE3TN_NO_FRAG_PIPELINE
           SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
           SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
           SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
           SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
-#else
-          SE3TN_MMA_KSTEP_PIPELINED(PT, CT, PXF, WTF)
-#endif
         }
 #undef PXF
 #undef WTF
@@ -343,14 +339,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gather_s2_kernel(const ConvArg
     if (MM == MM_F16X3) {
       SE3TN_MMA_SPLIT(PT, CT, PXF, WTF)
     } else {
-#ifdef SE3TN_NO_FRAG_PIPELINE
       SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
       SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
       SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
       SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
-#else
-      SE3TN_MMA_KSTEP_PIPELINED(PT, CT, PXF, WTF)
-#endif
     }
 #undef PXF
 #undef WTF
@@ -459,14 +451,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_splitk_kernel(const ConvArgs a
     if (MM == MM_F16X3) {
       SE3TN_MMA_SPLIT(PT, CT, PXF, WTF)
     } else {
-#ifdef SE3TN_NO_FRAG_PIPELINE
       SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
       SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
       SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
       SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
-#else
-      SE3TN_MMA_KSTEP_PIPELINED(PT, CT, PXF, WTF)
-#endif
     }
 #undef PXF
 #undef WTF

@@ -96,41 +96,6 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[j].w, pv_[i].w, acc[i][j], 0, 0, 0);    \
   }
 
-// The four 8-k groups of a K-step with the fragments of group g+1 fetched from LDS while the MFMAs of
-// group g run (two register sets; sched_barriers keep hipcc from sinking the prefetch back below the
-// MFMAs, which it otherwise does to shorten live ranges -- leaving every group to start on an exposed
-// ds_read latency).  PVEXPR(G) may use `i`, WVEXPR(G) may use `j`.
-#define SE3TN_MMA_LOADG(PTN, CTN, SET, G, PVEXPR, WVEXPR)                                             \
-  _Pragma("unroll") for (int i = 0; i < PTN; ++i) pf_[SET][i] = PVEXPR(G);                             \
-  _Pragma("unroll") for (int j = 0; j < CTN; ++j) wf_[SET][j] = WVEXPR(G);
-#define SE3TN_MMA_RUNG(PTN, CTN, SET)                                                                 \
-  _Pragma("unroll") for (int j = 0; j < CTN; ++j) _Pragma("unroll") for (int i = 0; i < PTN; ++i)     \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf_[SET][j].x, pf_[SET][i].x, acc[i][j], 0, 0, 0); \
-  _Pragma("unroll") for (int j = 0; j < CTN; ++j) _Pragma("unroll") for (int i = 0; i < PTN; ++i)     \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf_[SET][j].y, pf_[SET][i].y, acc[i][j], 0, 0, 0); \
-  _Pragma("unroll") for (int j = 0; j < CTN; ++j) _Pragma("unroll") for (int i = 0; i < PTN; ++i)     \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf_[SET][j].z, pf_[SET][i].z, acc[i][j], 0, 0, 0); \
-  _Pragma("unroll") for (int j = 0; j < CTN; ++j) _Pragma("unroll") for (int i = 0; i < PTN; ++i)     \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf_[SET][j].w, pf_[SET][i].w, acc[i][j], 0, 0, 0);
-#define SE3TN_MMA_KSTEP_PIPELINED(PTN, CTN, PVEXPR, WVEXPR)                                           \
-  {                                                                                                  \
-    float4 pf_[2][PTN], wf_[2][CTN];                                                                 \
-    SE3TN_MMA_LOADG(PTN, CTN, 0, 0, PVEXPR, WVEXPR)                                                   \
-    SE3TN_MMA_LOADG(PTN, CTN, 1, 1, PVEXPR, WVEXPR)                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    SE3TN_MMA_RUNG(PTN, CTN, 0)                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    SE3TN_MMA_LOADG(PTN, CTN, 0, 2, PVEXPR, WVEXPR)                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    SE3TN_MMA_RUNG(PTN, CTN, 1)                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    SE3TN_MMA_LOADG(PTN, CTN, 1, 3, PVEXPR, WVEXPR)                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    SE3TN_MMA_RUNG(PTN, CTN, 0)                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    SE3TN_MMA_RUNG(PTN, CTN, 1)                                                                       \
-  }
-
 // MM_F16X3: all four groups' fragments, then per 16-channel block kb: Whi*Phi + Whi*Plo + Wlo*Phi.
 // PVEXPR(G) / WVEXPR(G): float4 fragment of group G (may use `i` / `j`).
 #define SE3TN_MMA_SPLIT(PTN, CTN, PVEXPR, WVEXPR)                                                    \

@@ -305,14 +305,10 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
 #define FOG(G) ((G) == 0 ? fo0 : (G) == 1 ? fo1 : (G) == 2 ? fo2 : fo3)
 #define PXF(G) *reinterpret_cast<const float4*>(pP + i * 1024 + FOG(G))
 #define WTF(G) *reinterpret_cast<const float4*>(pW + j * 1024 + FOG(G))
-#ifdef SE3TN_NO_FRAG_PIPELINE
     SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
     SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
     SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
     SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
-#else
-    SE3TN_MMA_KSTEP_PIPELINED(PT, CT, PXF, WTF)
-#endif
 #undef PXF
 #undef WTF
 #undef FOG
