@@ -190,6 +190,22 @@ def test_winograd_path_vs_direct_and_oracle(se3, golden_dir, tile):
     print("F(%dx%d): max |d logit| Winograd vs direct = %.2e, |d trans| = %.2e" % (tile, tile, e0, e1))
 
 
+def test_batch_permutation_equivariance_bitwise(se3, model0):
+    """Size-independent property at BASELINE's batch: permuting the 64 pairs permutes the outputs BITWISE
+    (no pair's result depends on its neighbours or on where its pixels / Winograd tiles fall in a
+    workgroup tile: every kernel accumulates a row's K dimension in a fixed order)."""
+    model, _ = model0
+    A, B = Fx.net_inputs(31, 64)
+    Ac, Bc = A.cuda(), B.cuda()
+    model(Ac, Bc, return_feature=False)
+    l0 = model.engine.logits(64).clone()
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(5)).cuda()
+    model(Ac[perm].contiguous(), Bc[perm].contiguous(), return_feature=False)
+    l1 = model.engine.logits(64).clone()
+    assert torch.equal(l1, l0[perm])
+    assert not torch.equal(l0[0], l0[1])
+
+
 def _frame_to_cuda(rgb, depth):
     return torch.from_numpy(rgb).cuda(), torch.from_numpy(depth.view(np.int16)).cuda()
 
