@@ -204,6 +204,8 @@ def test_batch_permutation_equivariance_bitwise(se3, model0):
     l1 = model.engine.logits(64).clone()
     assert torch.equal(l1, l0[perm])
     assert not torch.equal(l0[0], l0[1])
+    model(Ac, Bc, return_feature=False)                 # and run to run: no atomics anywhere on the path
+    assert torch.equal(model.engine.logits(64), l0)
 
 
 def _frame_to_cuda(rgb, depth):
