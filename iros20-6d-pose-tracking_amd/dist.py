@@ -55,3 +55,18 @@ def gather_poses_async(local_poses, group=None):
                       dtype=local_poses.dtype, device=local_poses.device)
     work = dist.all_gather_into_tensor(out, local_poses.contiguous(), group=group, async_op=True)
     return out, work
+
+
+def shard_round_robin(items, rank, world):
+    """Object-level parallelism (BASELINE configs[4]: 21 YCB objects, per-object weights, 8 GPUs): item i is
+    owned by rank i % world -- objects differ ~3x in frame count, interleaving evens that out better than
+    contiguous blocks."""
+    return [it for i, it in enumerate(items) if i % world == rank]
+
+
+def gather_objects(obj, group=None):
+    """Every rank contributes one picklable object (e.g. {class_id: error arrays}); all ranks get the list
+    in rank order.  Host-side, once per evaluation: uses all_gather_object (no device traffic)."""
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, obj, group=group)
+    return out

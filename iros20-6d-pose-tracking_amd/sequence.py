@@ -197,3 +197,30 @@ def eval_ycbineoat(res_dir, data_dir, ycb_dir, objects=YCBINEOAT_OBJECTS):
         adds += a; adis += s_
     out.update(add_auc=auc(adds), adi_auc=auc(adis), n=len(adis))
     return out
+
+
+def eval_all_classes(per_class):
+    """eval_ycb.py:121-161 `eval_all`: per_class = {class_id: result of eval_one_class}; the overall ADD /
+    ADD-S AUC is VOCap over the CONCATENATED keyframe errors of all classes (not the mean of the AUCs)."""
+    adi = np.concatenate([per_class[k]["adi_errs"] for k in sorted(per_class)])
+    add = np.concatenate([per_class[k]["add_errs"] for k in sorted(per_class)])
+    return {"add_auc": metrics.VOCap(add) * 100, "adi_auc": metrics.VOCap(adi) * 100, "n": len(adi),
+            "per_class": {k: {"add_auc": per_class[k]["add_auc"], "adi_auc": per_class[k]["adi_auc"], "n": per_class[k]["n"]}
+                          for k in sorted(per_class)}}
+
+
+def eval_objects_parallel(class_ids, run_class, rank=0, world=1, group=None):
+    """BASELINE configs[4]: every rank (one per GPU) tracks and evaluates the classes it owns
+    (dist.shard_round_robin), `run_class(class_id)` -> result of eval_one_class (typically: build that
+    object's Tracker from its own checkpoint, get_results_ycb, eval_one_class); the per-class results are
+    all-gathered (host objects) and every rank returns the same eval_all_classes aggregate."""
+    from . import dist as D
+    mine = {int(cid): run_class(int(cid)) for cid in D.shard_round_robin(list(class_ids), rank, world)}
+    if world > 1:
+        merged = {}
+        for part in D.gather_objects(mine, group):
+            merged.update(part)
+    else:
+        merged = mine
+    assert sorted(merged) == sorted(int(c) for c in class_ids), "a class was not evaluated"
+    return eval_all_classes(merged)
