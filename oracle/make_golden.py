@@ -79,6 +79,37 @@ def gold_network(ref):
     print("network_big_n2: logits", caps2["t"].numpy(), caps2["r"].numpy())
 
 
+# (file, weight seed, head gain, input seed, n, input scale): logits / outputs only.  n >= 8 so that the
+# engine's DEFAULT large-batch algorithm (Winograd F(4x4,3x3) from SE3TN_WINOGRAD_DEFAULT_MIN_BATCH = 6
+# pairs) is what the GPU tests compare with these reference-made numbers; x40 / x150 inputs are the
+# magnitude real std.npy files produce; n = 64 is BASELINE configs[1]'s batch.
+LARGE_CASES = [
+    ("network_big_n8", 7, 0.002, 12, 8, 40.0),
+    ("network_huge_n8", 9, 0.0005, 13, 8, 150.0),
+    ("network_n64", 0, 0.05, 5, 64, 1.0),
+]
+
+
+def gold_network_large(ref):
+    for fname, wseed, gain, iseed, n, scale in LARGE_CASES:
+        sd = O.make_state_dict(wseed, head_gain=gain)
+        model = ref_model(ref, sd)
+        A, B = Fx.net_inputs(iseed, n, scale=scale)
+        caps = {}
+        h1 = model.trans_out[0].register_forward_hook(lambda m, i, o: caps.__setitem__("t", o.detach().clone()))
+        h2 = model.rot_out[0].register_forward_hook(lambda m, i, o: caps.__setitem__("r", o.detach().clone()))
+        with torch.no_grad():
+            out = model(A, B)
+        h1.remove(); h2.remove()
+        np.savez_compressed(os.path.join(OUT, fname + ".npz"), trans=out["trans"].numpy(), rot=out["rot"].numpy(),
+                            trans_logit=caps["t"].numpy(), rot_logit=caps["r"].numpy(),
+                            A_fp=np.array([float(A.double().sum()), float(A[0, 0, 0, 0])]),
+                            case=np.array([wseed, gain, iseed, n, scale]))
+        print(fname, "max |logit| %.3f  max |tanh| %.3f" % (
+            max(float(caps["t"].abs().max()), float(caps["r"].abs().max())),
+            max(float(out["trans"].abs().max()), float(out["rot"].abs().max()))))
+
+
 PRE_CASES = [
     # (name, frame_seed, translation, object_width)
     ("center", 3, (0.05, -0.02, 0.8), 250.0),       # bbox inside the frame
@@ -176,10 +207,11 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     ref = ref_shims.load()
-    gold_network(ref)
-    gold_preprocess(ref)
-    gold_pose_update(ref)
-    gold_on_track(ref)
+    jobs = {"network": gold_network, "network_large": gold_network_large, "preprocess": gold_preprocess,
+            "pose_update": gold_pose_update, "on_track": gold_on_track}
+    # `python -m oracle.make_golden network_large` regenerates one family only
+    for name in (sys.argv[1:] or list(jobs)):
+        jobs[name](ref)
     with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as f:
         f.write("generated by `python -m oracle.make_golden` from the reference tree at %s\n"
                 "torch %s numpy %s; cv2.resize(NEAREST)/cv2.Rodrigues via oracle/ref_shims.py shim "

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import fixtures as Fx
 from oracle import se3_oracle as O
-from oracle.make_golden import ON_TRACK_HEAD_GAIN, PRE_CASES, SUB
+from oracle.make_golden import LARGE_CASES, ON_TRACK_HEAD_GAIN, PRE_CASES, SUB
 
 NET_TOL = 1e-4     # north-star tolerance on (trans, rot)
 ACT_RTOL = 2e-5    # feature maps: f32 accumulation-order noise (oracle self-noise is ~2e-6)
@@ -188,6 +188,86 @@ def test_winograd_path_vs_direct_and_oracle(se3, golden_dir, tile):
     o5d = m(A5.cuda(), B5.cuda(), return_feature=False)
     e1 = _close("n5 trans vs direct", t5, o5d["trans"].cpu(), 0, 2e-5)
     print("F(%dx%d): max |d logit| Winograd vs direct = %.2e, |d trans| = %.2e" % (tile, tile, e0, e1))
+
+
+def _modes(se3, eng):
+    """The three arithmetic configurations of the engine: (name, enter, leave)."""
+    wmin, wtile = eng.get_winograd()
+    return [
+        ("f32 default (Winograd F(4x4) blocks from n >= %d)" % wmin, lambda: None, lambda: None),
+        ("f32 direct kernels only", lambda: eng.set_winograd(0), lambda: eng.set_winograd(wmin, wtile)),
+        ("f16x3", lambda: eng.set_precision(se3._lib.PREC_F16X3), lambda: eng.set_precision(se3._lib.PREC_F32)),
+    ]
+
+
+@pytest.mark.parametrize("case", LARGE_CASES[:2], ids=[c[0] for c in LARGE_CASES[:2]])
+def test_default_path_large_magnitude_inputs_vs_reference_golden(se3, golden_dir, case):
+    """n = 8 >= SE3TN_WINOGRAD_DEFAULT_MIN_BATCH: the engine's DEFAULT algorithm (Winograd F(4x4,3x3) for the
+    256/512-channel blocks) on inputs x40 / x150 (what real std.npy files produce) against logits made by
+    the reference's own code; the direct kernels and the f16x3 mode are held to the same numbers."""
+    fname, wseed, gain, iseed, n, scale = case
+    g = np.load(os.path.join(golden_dir, fname + ".npz"))
+    want = torch.from_numpy(np.concatenate([g["trans_logit"], g["rot_logit"]], 1))
+    sd = O.make_state_dict(wseed, head_gain=gain)
+    m = se3.Se3TrackNet(176, max_batch=n)
+    m.load_state_dict(sd)
+    m.cuda(0)
+    eng = m.engine
+    assert eng.get_winograd()[0] <= n, "the default threshold moved: regenerate the golden at a larger n"
+    A, B = Fx.net_inputs(iseed, n, scale=scale)
+    Ac, Bc = A.cuda(), B.cuda()
+    seen = []
+    for name, enter, leave in _modes(se3, eng):
+        enter()
+        try:
+            out = m(Ac, Bc, return_feature=False)
+            lg = eng.logits(n).cpu()
+            if name == "f16x3" and eng.overflow():
+                # documented behaviour: activations beyond the f16 range raise the flag and the caller reruns
+                # in float32 -- x150 inputs may do that; silently wrong numbers are what must not happen
+                print("%s: %s range guard fired (caller falls back to f32)" % (fname, name))
+                continue
+            e = _close(name + " logits vs reference golden", lg, want, 0, NET_TOL)
+            _close(name + " trans", out["trans"].cpu(), torch.from_numpy(g["trans"]), 0, NET_TOL)
+            _close(name + " rot", out["rot"].cpu(), torch.from_numpy(g["rot"]), 0, NET_TOL)
+            print("%s  %s: max |d logit| vs reference = %.2e" % (fname, name, e))
+            seen.append(lg)
+        finally:
+            leave()
+    assert not torch.equal(seen[0], seen[1]), "default and direct-only runs are identical: Winograd did not run"
+
+
+def test_batch64_every_pair_vs_oracle_and_reference_golden(se3, model0, golden_dir):
+    """BASELINE configs[1]'s batch: ALL 64 pairs of one call against the CPU oracle (run here on the same
+    inputs) and against logits the reference's own code produced (tests/golden/network_n64.npz), in the
+    default float32 configuration (Winograd blocks), with the direct kernels only, and in f16x3 mode."""
+    model, sd = model0
+    eng = model.engine
+    fname, wseed, gain, iseed, n, scale = LARGE_CASES[2]
+    assert (wseed, gain, n) == (0, 0.05, 64)
+    g = np.load(os.path.join(golden_dir, fname + ".npz"))
+    A, B = Fx.net_inputs(iseed, n, scale=scale)
+    ref = O.forward(sd, A, B)
+    want = torch.cat([ref["trans_logit"], ref["rot_logit"]], 1)
+    gold = torch.from_numpy(np.concatenate([g["trans_logit"], g["rot_logit"]], 1))
+    Ac, Bc = A.cuda(), B.cuda()
+    logits = []
+    for name, enter, leave in _modes(se3, eng):
+        enter()
+        try:
+            out = model(Ac, Bc, return_feature=False)
+            lg = eng.logits(n).cpu()
+            assert not eng.overflow()
+            e1 = _close(name + ": 64 logits vs oracle", lg, want, 0, NET_TOL)
+            e2 = _close(name + ": 64 logits vs reference golden", lg, gold, 0, NET_TOL)
+            for k in ("trans", "rot"):
+                _close(name + ": " + k + " vs oracle", out[k].cpu(), ref[k], 0, NET_TOL)
+                _close(name + ": " + k + " vs reference golden", out[k].cpu(), torch.from_numpy(g[k]), 0, NET_TOL)
+            print("batch 64, %s: max |d logit| vs oracle %.2e, vs reference golden %.2e" % (name, e1, e2))
+            logits.append(lg)
+        finally:
+            leave()
+    assert not torch.equal(logits[0], logits[1]) and not torch.equal(logits[1], logits[2])
 
 
 def test_batch_permutation_equivariance_bitwise(se3, model0):

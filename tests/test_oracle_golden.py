@@ -8,7 +8,7 @@ import torch
 
 from oracle import fixtures as Fx
 from oracle import se3_oracle as O
-from oracle.make_golden import ON_TRACK_HEAD_GAIN, PRE_CASES, SUB
+from oracle.make_golden import LARGE_CASES, ON_TRACK_HEAD_GAIN, PRE_CASES, SUB
 
 # oracle noise floor measured in SURVEY.md 8c: batch-1 vs batch-64 1.7e-6, layout 1.2e-6
 NET_TOL = 5e-6
@@ -50,6 +50,21 @@ def test_network_big_inputs(golden_dir):
     out = O.forward(sd, A, B)
     for k in ("trans", "rot", "trans_logit", "rot_logit"):
         np.testing.assert_allclose(out[k].numpy(), g[k], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", LARGE_CASES, ids=[c[0] for c in LARGE_CASES])
+def test_network_large_cases(golden_dir, case):
+    """n = 8 with x40 / x150 inputs and n = 64 (BASELINE configs[1]'s batch): the reference-made logits the
+    GPU tests hold the default (Winograd) path to."""
+    fname, wseed, gain, iseed, n, scale = case
+    g = _load(golden_dir, fname + ".npz")
+    sd = O.make_state_dict(wseed, head_gain=gain)
+    A, B = Fx.net_inputs(iseed, n, scale=scale)
+    assert abs(float(A.double().sum()) - g["A_fp"][0]) < 1e-6 and float(A[0, 0, 0, 0]) == g["A_fp"][1]
+    out = O.forward(sd, A, B)
+    for k in ("trans", "rot", "trans_logit", "rot_logit"):
+        assert g[k].shape == (n, 3)
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=0, atol=2e-5 if scale > 1 else NET_TOL)
 
 
 @pytest.mark.parametrize("case", PRE_CASES, ids=[c[0] for c in PRE_CASES])
