@@ -113,6 +113,11 @@ typedef struct se3tn_crop {
  * (se3tn_input_buffer), which are stored zero-bordered and consumed in place by se3tn_infer. */
 int se3tn_preprocess(se3tn_ctx* ctx, const se3tn_crop* crops, int n, float* out_nhwc,
                      void* stream);
+/* crop_bbox (Utils.py:320-359) ALONE: the zero-padded crop + cv2.resize(..., INTER_NEAREST) of one window,
+ * as raw images -- what Tracker.render_window returns for a full-frame renderer (predict.py:209-213) and
+ * what a caller of Tracker.dataset.processData feeds it.  crop->z_offset_mm / stats are ignored.
+ * Outputs (device): rgb uint8 [176,176,3], depth uint16 [176,176]. */
+int se3tn_crop_raw(se3tn_ctx* ctx, const se3tn_crop* crop, uint8_t* rgb_out, uint16_t* depth_out, void* stream);
 /* the context's own input buffers, which = 0 (A) / 1 (B).  Opaque layout ([max_batch,182,182,4],
  * 3-pixel zero border): only pass them to se3tn_preprocess (as out) and se3tn_infer (as A / B). */
 float* se3tn_input_buffer(se3tn_ctx* ctx, int which);

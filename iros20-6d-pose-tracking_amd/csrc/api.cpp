@@ -316,6 +316,9 @@ float* se3tn_input_buffer(se3tn_ctx* c, int which) { return !c ? nullptr : (whic
 int se3tn_preprocess(se3tn_ctx* c, const se3tn_crop* crops, int n, float* out, void* stream) {
   if (!c || c->device < 0 || !crops || !out || n < 0) return fail(SE3TN_E_ARG, "se3tn_preprocess: bad argument");
   if (!c->have_norm) return fail(SE3TN_E_STATE, "se3tn_preprocess: call se3tn_set_normalization first");
+  // the context's own input buffers hold max_batch images: more crops would run past them
+  if ((out == c->inA || out == c->inB) && n > c->max_batch)
+    return fail(SE3TN_E_ARG, "se3tn_preprocess: n > max_batch for the context's input buffer");
   for (int i = 0; i < n; ++i) {
     const se3tn_crop& k = crops[i];
     if (!k.rgb || !k.depth || k.H < 1 || k.W < 1 || k.right <= k.left || k.bottom <= k.top || (k.stats & ~1))
@@ -336,6 +339,14 @@ int se3tn_preprocess(se3tn_ctx* c, const se3tn_crop* crops, int n, float* out, v
     a.out = out + (size_t)i0 * (a.padded ? IN_P * IN_P : RES * RES) * 4;
     HIPCHK(launch_preprocess(a, (hipStream_t)stream));
   }
+  return SE3TN_OK;
+}
+
+int se3tn_crop_raw(se3tn_ctx* c, const se3tn_crop* k, uint8_t* rgb_out, uint16_t* depth_out, void* stream) {
+  if (!c || c->device < 0 || !k || !rgb_out || !depth_out) return fail(SE3TN_E_ARG, "se3tn_crop_raw: bad argument");
+  if (!k->rgb || !k->depth || k->H < 1 || k->W < 1 || k->right <= k->left || k->bottom <= k->top)
+    return fail(SE3TN_E_ARG, "se3tn_crop_raw: bad crop descriptor");
+  HIPCHK(launch_crop_raw(*k, rgb_out, depth_out, (hipStream_t)stream));
   return SE3TN_OK;
 }
 

@@ -517,11 +517,12 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvArgs a, int 
 
 // ---- launchers ---------------------------------------------------------------------------------
 template <typename K>
-static hipError_t set_lds(K kern, size_t lds, bool& done) {
-  if (done) return hipSuccess;
+static hipError_t set_lds(K kern, size_t lds, PerDeviceOnce& once) {
+  bool* done = once.current();
+  if (done && *done) return hipSuccess;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e == hipSuccess) done = true;
+  if (e == hipSuccess && done) *done = true;
   return e;
 }
 
@@ -532,7 +533,7 @@ static hipError_t launch_slab(const ConvArgs& a, hipStream_t st) {
   constexpr size_t lds = (size_t)(2 * SLABPX * 32 + 2 * BN * 32) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv3x3_slab_kernel<CIN, WM, WN, PT, CT, SLABPX, EPI, MM, OUTF, RESF>;
-  static bool attr = false;
+  static PerDeviceOnce attr;
   hipError_t e = set_lds(kern, lds, attr);
   if (e != hipSuccess) return e;
   const int tiles_m = (a.M + BM - 1) / BM;
@@ -547,7 +548,7 @@ template <int CIN, int EPI, int MM = MM_F32, int OUTF = FMT_F32>
 static hipError_t launch_gather(const ConvArgs& a, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * 256 * 32 * sizeof(float);
   auto kern = conv3x3_gather_s2_kernel<CIN, EPI, MM, OUTF>;
-  static bool attr = false;
+  static PerDeviceOnce attr;
   hipError_t e = set_lds(kern, lds, attr);
   if (e != hipSuccess) return e;
   const int tiles_m = (a.M + 127) / 128;
@@ -567,7 +568,7 @@ static hipError_t launch_splitk(const ConvArgs& a, int epi, int outf, int resf, 
   constexpr int BN = 64 * CT;
   constexpr size_t lds = (size_t)2 * (128 + BN) * 32 * sizeof(float);
   auto kern = conv3x3_splitk_kernel<CIN, STRIDE, CT, MM>;
-  static bool attr = false;
+  static PerDeviceOnce attr;
   hipError_t e = set_lds(kern, lds, attr);
   if (e != hipSuccess) return e;
   const int tiles_m = (a.M + 127) / 128;

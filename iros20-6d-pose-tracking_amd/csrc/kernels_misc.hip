@@ -108,6 +108,34 @@ hipError_t launch_preprocess(const CropArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// crop_bbox alone (Utils.py:320-359): same window / index rule as preprocess_kernel, raw integer outputs
+__global__ __launch_bounds__(256) void crop_raw_kernel(const se3tn_crop c, uint8_t* __restrict__ rgb_out,
+                                                        uint16_t* __restrict__ depth_out) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= RES * RES) return;
+  const int y = p / RES, x = p - y * RES;
+  const int cw = c.right - c.left, chh = c.bottom - c.top;
+  const double ifx = 1.0 / ((double)RES / (double)cw);
+  const double ify = 1.0 / ((double)RES / (double)chh);
+  int sx = (int)floor((double)x * ifx); sx = sx < cw - 1 ? sx : cw - 1;
+  int sy = (int)floor((double)y * ify); sy = sy < chh - 1 ? sy : chh - 1;
+  const int fx = c.left + sx, fy = c.top + sy;
+  uint8_t r = 0, g = 0, b = 0;
+  uint16_t d = 0;
+  if ((unsigned)fx < (unsigned)c.W && (unsigned)fy < (unsigned)c.H) {
+    const size_t q = (size_t)fy * c.W + fx;
+    r = c.rgb[q * 3]; g = c.rgb[q * 3 + 1]; b = c.rgb[q * 3 + 2];
+    d = c.depth[q];
+  }
+  rgb_out[p * 3] = r; rgb_out[p * 3 + 1] = g; rgb_out[p * 3 + 2] = b;
+  depth_out[p] = d;
+}
+
+hipError_t launch_crop_raw(const se3tn_crop& c, uint8_t* rgb_out, uint16_t* depth_out, hipStream_t st) {
+  hipLaunchKernelGGL(crop_raw_kernel, dim3((RES * RES + 255) / 256), dim3(256), 0, st, c, rgb_out, depth_out);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Tail: one 256-thread workgroup per pair.  head = zero-bordered [n,13,13,1024] (trans 0-511 | rot
 // 512-1023): summing all 169 rows equals summing the 121 interior pixels.

@@ -159,11 +159,24 @@ struct CropArgs {  // one launch handles up to MAX crops
   int* overflow;
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies per DEVICE: a launcher remembers which device
+// ordinals it has already raised the limit on (several contexts on different GPUs in one process).
+struct PerDeviceOnce {
+  bool done[64] = {};
+  // returns the flag of the calling thread's current device (nullptr if the ordinal cannot be read)
+  bool* current() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    return &done[dev];
+  }
+};
+
 // launchers (defined in the .hip files)
 // NCHW [n,4,176,176] (nchw != 0) or plain NHWC [n,176,176,4] -> interior of the padded [n,182,182,4]
 hipError_t launch_to_padded_input(const float* in, float* out, int n, int nchw, int split, int* overflow,
                                   hipStream_t st);
 hipError_t launch_preprocess(const CropArgs& a, hipStream_t st);
+hipError_t launch_crop_raw(const se3tn_crop& c, uint8_t* rgb_out, uint16_t* depth_out, hipStream_t st);
 // wscale != nullptr selects the f16x3 stem (split pixels, split weights w)
 hipError_t launch_stem(const float* inA, const float* inB, const float* w, const float* bias,
                        const float* wscale, float* out, int n, hipStream_t st);

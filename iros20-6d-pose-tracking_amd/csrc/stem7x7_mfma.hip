@@ -259,15 +259,16 @@ __global__ __launch_bounds__(512, 2) void stem7x7_slab_kernel(const StemArgs a) 
 hipError_t launch_stem(const float* inA, const float* inB, const float* w, const float* bias,
                        const float* wscale, float* out, int n, hipStream_t st) {
   constexpr size_t lds = WBYTES + 2 * SLAB_BYTES;  // 128,000 B
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  bool* done = attr.current();
+  if (!done || !*done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7x7_slab_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7x7_slab_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr = true;
+    if (done) *done = true;
   }
   StemArgs a;
   a.in[0] = inA; a.in[1] = inB; a.w = w; a.bias = bias; a.wscale = wscale; a.out = out; a.n = n;

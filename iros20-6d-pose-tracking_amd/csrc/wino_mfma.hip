@@ -344,15 +344,16 @@ hipError_t launch_wino_weights(const float* packed, float* U, int cin, int cout,
 
 template <int CIN, int WM, int WN, int PT, int CT>
 static hipError_t launch_gemm(const WinoArgs& a, hipStream_t st) {
-  static bool attr = false;
+  static PerDeviceOnce attr;
   auto kern = wino_gemm_kernel<CIN, WM, WN, PT, CT>;
   constexpr int BM = WM * PT * 32, BN = WN * CT * 32;
   const size_t lds = 2 * (BM + BN) * 32 * sizeof(float);
-  if (!attr) {
+  bool* done = attr.current();
+  if (!done || !*done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr = true;
+    if (done) *done = true;
   }
   const int grid = (a.Cout / BN) * ((a.T + BM - 1) / BM) * a.groups * a.nf;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);

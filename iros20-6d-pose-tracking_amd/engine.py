@@ -159,6 +159,23 @@ class Engine:
         ptr = out.data_ptr() if torch.is_tensor(out) else int(out)
         check(self.lib.se3tn_preprocess(self._h, arr, n, C.c_void_p(ptr), _stream_ptr()), "se3tn_preprocess")
 
+    def crop_raw(self, rgb, depth, window):
+        """crop_bbox (Utils.py:320-359) alone: numpy rgb u8 [H,W,3] + depth u16 [H,W], window (left, top, right,
+        bottom) -> numpy (rgb u8 [176,176,3], depth u16 [176,176])."""
+        dev = "cuda:%d" % self.device
+        rgb_d = torch.from_numpy(np.ascontiguousarray(rgb, dtype=np.uint8)).to(dev)
+        dep_d = torch.from_numpy(np.ascontiguousarray(depth, dtype=np.uint16).view(np.int16)).to(dev)
+        assert rgb_d.dim() == 3 and rgb_d.shape[2] == 3 and tuple(dep_d.shape) == tuple(rgb_d.shape[:2])
+        c = Crop()
+        c.rgb = rgb_d.data_ptr(); c.depth = dep_d.data_ptr()
+        c.H, c.W = int(rgb_d.shape[0]), int(rgb_d.shape[1])
+        c.left, c.top, c.right, c.bottom = [int(v) for v in window]
+        out_rgb = torch.empty((RES, RES, 3), dtype=torch.uint8, device=dev)
+        out_d = torch.empty((RES, RES), dtype=torch.int16, device=dev)
+        check(self.lib.se3tn_crop_raw(self._h, C.byref(c), C.c_void_p(out_rgb.data_ptr()), C.c_void_p(out_d.data_ptr()),
+                                      _stream_ptr()), "se3tn_crop_raw")
+        return out_rgb.cpu().numpy(), out_d.cpu().numpy().view(np.uint16)
+
     def infer(self, A, B, n, layout=NCHW, trans=None, rot=None, poseA=None, poseB=None):
         def p(x):
             if x is None:

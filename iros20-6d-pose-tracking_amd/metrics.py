@@ -29,21 +29,26 @@ def adi(pred, gt, model, workers=-1):
     return float(d.mean())
 
 
-def VOCap(rec):
-    """eval_ycb.py:45-64.  Raises IndexError when no error is below 0.1 (as the reference does)."""
-    rec = np.sort(np.array(rec))
-    n = len(rec)
-    prec = np.arange(1, n + 1) / float(n)
-    rec = rec.reshape(-1)
-    prec = prec.reshape(-1)
-    index = np.where(rec < 0.1)[0]
-    rec = rec[index]
-    prec = prec[index]
-    mrec = [0, *list(rec), 0.1]
-    mpre = [0, *list(prec), prec[-1]]
-    for i in range(1, len(mpre)):
-        mpre[i] = max(mpre[i], mpre[i - 1])
-    mpre = np.array(mpre)
-    mrec = np.array(mrec)
-    i = np.where(mrec[1:] != mrec[0:len(mrec) - 1])[0] + 1
-    return float(np.sum((mrec[i] - mrec[i - 1]) * mpre[i]) * 10)
+def VOCap(errors, max_err=0.1):
+    """Area under the accuracy-vs-error-threshold curve for thresholds in [0, max_err], scaled so that a
+    perfect result gives 1 (the YCB-Video toolbox metric the reference reports x100; same numbers as
+    eval_ycb.py:45-64).  accuracy(t) = fraction of ALL errors <= t, a step function that jumps at every
+    error below max_err; the area is summed as (gap between consecutive jump positions) x (accuracy after
+    the jump), the last gap running up to max_err.  Ties contribute zero-width gaps, so they need no
+    special casing.  Raises IndexError when no error is below max_err, as the reference does (a lost track);
+    `auc()` maps that case to 0."""
+    e = np.sort(np.asarray(errors, np.float64).ravel())
+    k = int(np.searchsorted(e, max_err, side="left"))        # errors strictly below the cap
+    if k == 0:
+        raise IndexError("VOCap: no error below %g" % max_err)
+    x = np.concatenate(([0.0], e[:k], [max_err]))
+    acc = np.concatenate((np.arange(1, k + 1, dtype=np.float64) / e.size, [k / float(e.size)]))
+    return float(np.dot(np.diff(x), acc) / max_err)
+
+
+def auc(errors, max_err=0.1):
+    """VOCap x 100 with the lost-track / empty case reported as 0.0 instead of an exception."""
+    try:
+        return VOCap(errors, max_err) * 100.0
+    except IndexError:
+        return 0.0

@@ -16,6 +16,13 @@ class Se3TrackNet:
         self._sd = None
         self.engine = None
 
+    @classmethod
+    def from_engine(cls, engine):
+        """The callable ``Tracker.model`` (predict.py:270-271): shares the Tracker's engine and weights."""
+        m = cls(176, engine.max_batch)
+        m.engine = engine
+        return m
+
     def load_state_dict(self, state_dict, strict=True):
         self._sd = state_dict
         if self.engine is not None:

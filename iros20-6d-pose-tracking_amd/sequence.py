@@ -62,19 +62,20 @@ def predict_sequence_ycb(tracker, seq_dir, class_id, out_dir, start_frame=0, rei
            "hz": (len(pred_poses) - 1) / t_track if t_track > 0 else float("nan")}
     if adi_errs:
         res.update(add_errs=np.array(add_errs), adi_errs=np.array(adi_errs))
-        for name, errs in (("add_auc", add_errs), ("adi_auc", adi_errs)):
-            try:
-                res[name] = metrics.VOCap(np.array(errs)) * 100
-            except IndexError:  # no frame below 0.1 m: the reference's VOCap raises
-                res[name] = 0.0
+        res["add_auc"] = metrics.auc(add_errs)    # 0.0 when no frame is below 0.1 m (the reference's VOCap raises)
+        res["adi_auc"] = metrics.auc(adi_errs)
     return res
 
 
-def get_results_ycb(tracker, ycb_dir, class_id, out_dir, seq_ids=None, max_frames=None):
-    """The loop of predict.py:299-443 `getResultsYcb` (GT initialisation, no re-init, no video): every
-    sequence under <ycb_dir>/data_organized/ that has pose_gt/<class_id>/ is tracked from its first
-    frame and written as <out_dir>/seq<ID>/%07d.txt -- the layout eval_one_class / the reference's
-    eval_ycb.py:95-96 parse (file index = frame id - 1).  Returns {seq_id: n_poses}."""
+YCB_TEST_SEQUENCES = tuple(range(48, 60))   # predict.py:349 skips every video outside 0048..0059
+
+
+def get_results_ycb(tracker, ycb_dir, class_id, out_dir, seq_ids=YCB_TEST_SEQUENCES, max_frames=None):
+    """The loop of predict.py:299-443 `getResultsYcb` (GT initialisation, no re-init, no video): every TEST
+    sequence (48..59 by default, as predict.py:349; seq_ids=None takes every directory) under
+    <ycb_dir>/data_organized/ that has pose_gt/<class_id>/ is tracked from its first frame and written as
+    <out_dir>/seq<ID>/%07d.txt -- the layout eval_one_class / the reference's eval_ycb.py:95-96 parse
+    (file index = frame id - 1).  Returns {seq_id: n_poses}."""
     root = os.path.join(ycb_dir, "data_organized")
     done = {}
     for seq_dir in sorted(glob.glob(os.path.join(root, "*"))):
@@ -86,12 +87,12 @@ def get_results_ycb(tracker, ycb_dir, class_id, out_dir, seq_ids=None, max_frame
         rgb_files = sorted(glob.glob(os.path.join(seq_dir, "color", "*")))
         depth_files = sorted(glob.glob(os.path.join(seq_dir, "depth_filled", "*")))
         gt_files = sorted(glob.glob(os.path.join(seq_dir, "pose_gt", str(class_id), "*")))
+        assert len(rgb_files) == len(depth_files) == len(gt_files) > 0, "incomplete sequence directory %s" % seq_dir
         n = len(rgb_files) if max_frames is None else min(len(rgb_files), max_frames)
         prev_pose = np.loadtxt(gt_files[0])
         pred = [prev_pose]
         for i in range(1, n):
-            cur = tracker.on_track(prev_pose, read_rgb(rgb_files[i]), read_depth_mm(depth_files[i]),
-                                   gt_A_in_cam=None, gt_B_in_cam=np.loadtxt(gt_files[i]))
+            cur = tracker.on_track(prev_pose, read_rgb(rgb_files[i]), read_depth_mm(depth_files[i]))
             prev_pose = cur.copy()
             pred.append(cur)
         sdir = os.path.join(out_dir, "seq%d" % seq_id)
@@ -125,7 +126,7 @@ def eval_one_class(res_dir, ycb_dir, class_id):
         add_errs.append(metrics.add(pred, gt, model_pts))
     assert len(adi_errs) > 0, "no keyframe among the result files"
     adi_errs = np.sort(np.array(adi_errs)); add_errs = np.sort(np.array(add_errs))
-    return {"add_auc": metrics.VOCap(add_errs) * 100, "adi_auc": metrics.VOCap(adi_errs) * 100,
+    return {"add_auc": metrics.auc(add_errs), "adi_auc": metrics.auc(adi_errs),
             "adi_errs": adi_errs, "add_errs": add_errs, "n": len(adi_errs)}
 
 
@@ -182,11 +183,7 @@ def eval_ycbineoat(res_dir, data_dir, ycb_dir, objects=YCBINEOAT_OBJECTS):
             class_res[obj]["add"].append(metrics.add(pred, gt, models[obj]))
             class_res[obj]["add-s"].append(metrics.adi(pred, gt, models[obj]))
 
-    def auc(errs):
-        try:
-            return metrics.VOCap(np.array(errs)) * 100
-        except IndexError:   # nothing below 0.1 m (the reference's VOCap raises); empty lists too
-            return 0.0
+    auc = metrics.auc   # 0.0 when nothing is below 0.1 m (the reference's VOCap raises) or the list is empty
     out = {"per_object": {}, "n": 0}
     adds, adis = [], []
     for obj in objects:
@@ -204,7 +201,7 @@ def eval_all_classes(per_class):
     ADD-S AUC is VOCap over the CONCATENATED keyframe errors of all classes (not the mean of the AUCs)."""
     adi = np.concatenate([per_class[k]["adi_errs"] for k in sorted(per_class)])
     add = np.concatenate([per_class[k]["add_errs"] for k in sorted(per_class)])
-    return {"add_auc": metrics.VOCap(add) * 100, "adi_auc": metrics.VOCap(adi) * 100, "n": len(adi),
+    return {"add_auc": metrics.auc(add), "adi_auc": metrics.auc(adi), "n": len(adi),
             "per_class": {k: {"add_auc": per_class[k]["add_auc"], "adi_auc": per_class[k]["adi_auc"], "n": per_class[k]["n"]}
                           for k in sorted(per_class)}}
 
@@ -215,12 +212,22 @@ def eval_objects_parallel(class_ids, run_class, rank=0, world=1, group=None):
     object's Tracker from its own checkpoint, get_results_ycb, eval_one_class); the per-class results are
     all-gathered (host objects) and every rank returns the same eval_all_classes aggregate."""
     from . import dist as D
-    mine = {int(cid): run_class(int(cid)) for cid in D.shard_round_robin(list(class_ids), rank, world)}
+    mine, failure = {}, None
+    for cid in D.shard_round_robin(list(class_ids), rank, world):
+        try:
+            mine[int(cid)] = run_class(int(cid))
+        except Exception as e:   # noqa: BLE001 -- every rank must still enter the collective below
+            failure = "rank %d, class %d: %r" % (rank, int(cid), e)
+            break
     if world > 1:
-        merged = {}
-        for part in D.gather_objects(mine, group):
+        merged, failures = {}, []
+        for part, fail in D.gather_objects((mine, failure), group):
             merged.update(part)
+            if fail:
+                failures.append(fail)
     else:
-        merged = mine
+        merged, failures = mine, [failure] if failure else []
+    if failures:   # raised on EVERY rank, after the gather: nobody is left waiting in a collective
+        raise RuntimeError("eval_objects_parallel: " + "; ".join(failures))
     assert sorted(merged) == sorted(int(c) for c in class_ids), "a class was not evaluated"
     return eval_all_classes(merged)

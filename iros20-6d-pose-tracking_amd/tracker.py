@@ -1,6 +1,6 @@
 """Drop-in for the reference's ``predict.Tracker`` (predict.py:127-296): same constructor
 arguments, ``on_track`` signature / return value and the attributes callers read (``K``,
-``object_cloud``, ``object_width``, ``dataset``-less).  The arithmetic of on_track runs on the GPU
+``object_cloud``, ``object_width``, ``dataset`` with processData / processPredict, callable ``model``).  The arithmetic of on_track runs on the GPU
 through the C ABI: se3tn_preprocess -> se3tn_infer (network + pose update); only compute_bbox is
 host float64 exactly as the reference.  Rendering (predict.py:193-215) is out of the kernel scope:
 a renderer object is injected (``renderer.render(ob_in_cam, K, window) -> rgb u8, depth u16``)."""
@@ -8,7 +8,18 @@ import numpy as np
 import torch
 
 from . import utils as U
+from .dataset import TrackDataset
 from .engine import Engine, NHWC
+from .se3_tracknet import Se3TrackNet
+
+
+def _depth_u16(depth, rgb):
+    """HxW depth in millimetres as the int16-viewed uint16 array the engine takes.  The reference casts with
+    .astype(np.uint16) (predict.py:410-412 callers); a wider dtype must be CONVERTED, never byte-reinterpreted."""
+    d = np.asarray(depth)
+    if d.shape != np.asarray(rgb).shape[:2]:
+        raise ValueError("depth %s does not match rgb %s" % (d.shape, np.asarray(rgb).shape))
+    return np.ascontiguousarray(d, dtype=np.uint16).view(np.int16)
 
 
 class Tracker:
@@ -42,7 +53,11 @@ class Tracker:
         self.trans_normalizer = float(trans_normalizer)
         self.rot_normalizer = float(rot_normalizer)
         self.engine.set_normalizers(self.trans_normalizer, self.rot_normalizer)
-        self.model = self.engine  # attribute name kept for callers that only check it exists
+        # predict.py:270-271 `prediction = self.model(dataA, dataB)`: float32 CUDA [N,4,176,176] -> the reference's dict
+        self.model = Se3TrackNet.from_engine(self.engine)
+        # predict.py:189-191: the inner pre / post boundary (processData / processPredict)
+        self.dataset = TrackDataset(self.engine, self.mean, self.std, dataset_info, self.trans_normalizer,
+                                    self.rot_normalizer)
         self.renderer = renderer
         if renderer is None and model_path is not None and model_path.endswith(".ply"):
             # the reference builds a VispyRenderer from the .ply here (predict.py:180-182); ours is the
@@ -70,14 +85,30 @@ class Tracker:
             self.engine.enable_graphs(True)
 
     def render_window(self, ob2cam):
-        """predict.py:193-215.  Delegates to the injected renderer with the crop window."""
+        """predict.py:193-215.  Three renderer protocols, in the reference's order:
+          * VispyRenderer-like objects (``update_cam_mat`` + ``render_image``): driven exactly as
+            predict.py:201-208 does -- y-flipped bbox (scale (1000,-1000,1000)), ``update_cam_mat(K, left,
+            right, bottom, top)``, ``render_image(ob2cam_gl)``;
+          * the HIP rasteriser and any injected ``render(ob2cam, K, window)`` object: the same y-flipped
+            window (left, top, right, bottom) is passed;
+          * full-frame renderers in the style of offscreen_renderer.Renderer (``render([ob2cam])`` ->
+            rgb HxWx3, depth HxW metres; predict.py:209-213): depth -> uint16 mm, then the crop + NEAREST
+            resize of crop_bbox on the device (se3tn_crop_raw)."""
         if self.renderer is None:
             raise RuntimeError("Tracker.render_window: no renderer injected (rendering is outside the HIP hot path)")
         from .renderer import HipRenderer
-        if isinstance(self.renderer, HipRenderer):
-            return self.renderer.render(ob2cam, self.K, HipRenderer.gl_window(ob2cam, self.K, self.object_width))
-        bbox = U.compute_bbox(ob2cam, self.K, self.object_width, scale=(1000, 1000, 1000))
-        return self.renderer.render(ob2cam, self.K, U.crop_window(bbox))
+        ob2cam = np.asarray(ob2cam, np.float64)
+        win = HipRenderer.gl_window(ob2cam, self.K, self.object_width)      # left, top, right, bottom (GL image)
+        if hasattr(self.renderer, "update_cam_mat") and hasattr(self.renderer, "render_image"):
+            glcam_in_cvcam = np.diag([1.0, -1.0, -1.0, 1.0])
+            self.renderer.update_cam_mat(self.K, win[0], win[2], win[3], win[1])
+            return self.renderer.render_image(np.linalg.inv(glcam_in_cvcam).dot(ob2cam))
+        if getattr(self.renderer, "full_frame", False):
+            rgb, depth = self.renderer.render([ob2cam])
+            depth = (np.asarray(depth) * 1000).astype(np.uint16)
+            bbox = U.compute_bbox(ob2cam, self.K, self.object_width, scale=(1000, 1000, 1000))
+            return self.engine.crop_raw(rgb, depth, U.crop_window(bbox))
+        return self.renderer.render(ob2cam, self.K, win)
 
     def on_track(self, prev_pose, current_rgb, current_depth, gt_A_in_cam=None, gt_B_in_cam=None,
                  debug=False, samples=1):
@@ -98,14 +129,14 @@ class Tracker:
             rgbA_d = torch.from_numpy(np.ascontiguousarray(rgbA)).to(dev, non_blocking=True)
             depA_d = torch.from_numpy(np.ascontiguousarray(depthA).astype(np.uint16).view(np.int16)).to(dev, non_blocking=True)
         rgb_d = torch.from_numpy(np.ascontiguousarray(current_rgb)).to(dev, non_blocking=True)
-        dep_d = torch.from_numpy(np.ascontiguousarray(current_depth).view(np.int16)).to(dev, non_blocking=True)
+        dep_d = torch.from_numpy(_depth_u16(current_depth, current_rgb)).to(dev, non_blocking=True)
         z_mm = float(prev_pose[2, 3]) * 1000
         res = self.image_size[0]
-        n = int(samples)
+        # the reference evaluates `samples` IDENTICAL hypotheses (only i == 0 sets sample_pose, predict.py:229-231)
+        # and returns the first: any count beyond the engine's batch capacity adds nothing -- clamp, never overrun
+        n = max(1, min(int(samples), self.engine.max_batch))
         cropA = dict(rgb=rgbA_d, depth=depA_d, window=(0, 0, res, res), z_offset_mm=z_mm, stats=0)
         cropB = dict(rgb=rgb_d, depth=dep_d, window=U.crop_window(bb), z_offset_mm=z_mm, stats=1)
-        # the reference evaluates `samples` identical hypotheses (only i==0 sets sample_pose,
-        # predict.py:229-231) and returns the first
         self.engine.preprocess([cropA] * n, self.engine.input_buffer_ptr(0))
         self.engine.preprocess([cropB] * n, self.engine.input_buffer_ptr(1))
         self._poseA[:n].copy_(torch.from_numpy(np.tile(prev_pose.reshape(1, 16), (n, 1))), non_blocking=True)
@@ -141,7 +172,7 @@ class Tracker:
                 rgbA_d = torch.from_numpy(np.ascontiguousarray(rgbA)).to(dev)
                 depA_d = torch.from_numpy(np.ascontiguousarray(depthA).astype(np.uint16).view(np.int16)).to(dev)
             rgb_d = torch.from_numpy(np.ascontiguousarray(rgbs[i])).to(dev, non_blocking=True)
-            dep_d = torch.from_numpy(np.ascontiguousarray(depths[i]).view(np.int16)).to(dev, non_blocking=True)
+            dep_d = torch.from_numpy(_depth_u16(depths[i], rgbs[i])).to(dev, non_blocking=True)
             keep += [rgbA_d, depA_d, rgb_d, dep_d]
             z_mm = float(poses[i, 2, 3]) * 1000
             cropsA.append(dict(rgb=rgbA_d, depth=depA_d, window=(0, 0, 176, 176), z_offset_mm=z_mm, stats=0))

@@ -62,6 +62,16 @@ def _worker(rank, world, port, q):
         assert ran == [c for i, c in enumerate(range(1, 8)) if i % world == rank]
         assert agg["n"] == sum(5 + c for c in range(1, 8)) and sorted(agg["per_class"]) == list(range(1, 8))
         assert 0 < agg["adi_auc"] <= 100 and agg["adi_auc"] > agg["add_auc"]
+        # a class that fails on ONE rank: every rank still enters the gather and every rank raises (no hang)
+        def run_class_bad(cid):
+            if cid == 2:
+                raise IndexError("lost track")
+            return run_class(cid)
+        try:
+            S.eval_objects_parallel(range(1, 5), run_class_bad, rank, world)
+            raise AssertionError("expected RuntimeError on rank %d" % rank)
+        except RuntimeError as e:
+            assert "class 2" in str(e) and "lost track" in str(e)
         q.put((rank, "ok", agg["adi_auc"]))
     except Exception as e:  # noqa
         q.put((rank, repr(e)))

@@ -1,0 +1,172 @@
+"""GPU: the reference's INNER boundaries on the drop-in Tracker: `Tracker.dataset.processData /
+processPredict`, the callable `Tracker.model`, `render_window`'s three renderer protocols, `samples`, and
+the depth dtype handling -- each through the goldens the reference's own code produced."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fixtures as Fx
+from oracle import se3_oracle as O
+from oracle.make_golden import ON_TRACK_HEAD_GAIN, PRE_CASES
+
+
+@pytest.fixture(scope="module")
+def se3():
+    import se3tracknet_amd
+    return se3tracknet_amd
+
+
+class _Stub:
+    def __init__(self):
+        self.windows = []
+
+    def render(self, ob2cam, K, window):
+        self.windows.append(tuple(int(v) for v in window))
+        return Fx.synthetic_render(130, ob2cam[2, 3])
+
+
+@pytest.fixture(scope="module")
+def tracker(se3):
+    sd = O.make_state_dict(0, head_gain=ON_TRACK_HEAD_GAIN)
+    mean, std = Fx.mean_std(0)
+    return se3.Tracker(Fx.DATASET_INFO, mean, std, {"state_dict": sd}, renderer=_Stub(), max_samples=4), sd
+
+
+@pytest.mark.parametrize("case", PRE_CASES, ids=[c[0] for c in PRE_CASES])
+def test_dataset_processData_bit_exact_vs_reference_golden(se3, tracker, golden_dir, case):
+    """crop_raw (= crop_bbox) then dataset.processData(...)[0]: the reference's two-step pre-processing
+    (predict.py:234,264), byte for byte what its own code produced."""
+    trk, _ = tracker
+    name, fseed, t, width = case
+    g = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    rgb, depth = Fx.synthetic_frame(fseed)
+    P = Fx.pose(fseed, t)
+    rgbA, depthA = Fx.synthetic_render(fseed + 100, t[2])
+    bb = se3.compute_bbox(P, Fx.K_YCB, width)
+    rgbB, depthB = trk.engine.crop_raw(rgb, depth, se3.crop_window(bb))
+    assert rgbB.dtype == np.uint8 and depthB.dtype == np.uint16 and rgbB.shape == (176, 176, 3)
+    assert Fx.sha(rgbB) == str(g[name + "_rgbB_sha"]) and Fx.sha(depthB) == str(g[name + "_depthB_sha"])
+    ret = trk.dataset.processData(rgbA, depthA, P, rgbB, depthB, np.eye(4))
+    assert len(ret) == 6
+    sample, labels, vizA, vizB, maskA, maskB = ret
+    a, b = sample[0], sample[1]
+    assert a.dtype == torch.float32 and tuple(a.shape) == (4, 176, 176) and not a.is_cuda
+    assert Fx.sha(a.numpy()) == str(g[name + "_dataA_sha"])
+    assert Fx.sha(b.numpy()) == str(g[name + "_dataB_sha"])
+    assert (maskA == (depthA > 100)).all() and (maskB == (depthB > 100)).all() and maskA.dtype == np.uint8
+    assert labels[0].shape == (3,) and labels[1].shape == (3,) and vizA.dtype == np.uint8
+
+
+def test_dataset_labels_and_processPredict_vs_reference_golden(se3, tracker, golden_dir):
+    trk, _ = tracker
+    g = np.load(os.path.join(golden_dir, "pose_update.npz"))
+    keep = (trk.dataset.trans_normalizer, trk.dataset.rot_normalizer)
+    try:
+        for i in range(len(g["A"])):
+            trk.dataset.trans_normalizer, trk.dataset.rot_normalizer = float(g["norm"][i, 0]), float(g["norm"][i, 1])
+            B = trk.dataset.processPredict(g["A"][i], (g["trans"][i], g["rot"][i]))
+            assert B.dtype == np.float64 and np.abs(B - g["B"][i]).max() < 5e-16
+            # the label math inverts the pose update: labels of (A -> B) are the (trans, rot) that produced B
+            rgbA, depthA = Fx.synthetic_render(5, 0.8)
+            lab = trk.dataset.processData(rgbA, depthA, g["A"][i], rgbA, depthA, g["B"][i])[1]
+            assert np.abs(lab[0] - g["trans"][i]).max() < 1e-6
+            assert np.abs(lab[1] - g["rot"][i]).max() < 5e-6      # R was rounded to float32 by cv2.Rodrigues
+    finally:
+        trk.dataset.trans_normalizer, trk.dataset.rot_normalizer = keep
+
+
+def test_model_is_callable_and_stages_compose_to_on_track(se3, tracker, golden_dir):
+    """predict.py:229-277 driven stage by stage through the drop-in's attributes == Tracker.on_track ==
+    the reference-made golden of frame 0."""
+    trk, sd = tracker
+    g = np.load(os.path.join(golden_dir, "on_track.npz"))
+    P = Fx.pose(3)
+    rgb, depth = Fx.synthetic_frame(30)
+    trk.renderer = _Stub()
+    bb = se3.compute_bbox(P, trk.K, trk.object_width)
+    assert (bb == g["bbox"][0]).all()
+    rgbB, depthB = trk.engine.crop_raw(rgb, depth, se3.crop_window(bb))
+    rgbA, depthA = trk.render_window(P)
+    sample = trk.dataset.processData(rgbA, depthA, P, rgbB, depthB, np.eye(4))[0]
+    dataA = torch.cat([sample[0].unsqueeze(0)], dim=0).cuda().float()
+    dataB = torch.cat([sample[1].unsqueeze(0)], dim=0).cuda().float()
+    with torch.no_grad():
+        prediction = trk.model(dataA, dataB)
+    assert set(prediction) >= {"trans", "rot", "feature"} and tuple(prediction["feature"].shape) == (1, 256, 22, 22)
+    trans_pred = prediction["trans"][0].data.cpu().numpy(); rot_pred = prediction["rot"][0].data.cpu().numpy()
+    pose = trk.dataset.processPredict(P, (trans_pred, rot_pred))
+    assert np.abs(trans_pred - g["trans"][0]).max() < 1e-4 and np.abs(rot_pred - g["rot"][0]).max() < 1e-4
+    assert np.abs(pose - g["poses"][1]).max() < 1e-5
+    trk.renderer = _Stub()
+    fused = trk.on_track(P, rgb, depth)
+    assert np.abs(fused - pose).max() < 1e-7        # same kernels, same inputs; device vs host pose composition
+
+
+def test_render_window_protocols(se3, tracker):
+    trk, _ = tracker
+    P = Fx.pose(3, (0.04, -0.03, 0.75))
+    # (1) injected render(ob2cam, K, window): the y-FLIPPED window of predict.py:201-206
+    stub = _Stub()
+    trk.renderer = stub
+    trk.render_window(P)
+    bb = O.compute_bbox(P, trk.K, trk.object_width, scale=(1000, -1000, 1000))
+    want = (int(bb[:, 1].min()), int(bb[:, 0].min()), int(bb[:, 1].max()), int(bb[:, 0].max()))
+    assert stub.windows == [want]
+    plain = O.compute_bbox(P, trk.K, trk.object_width, scale=(1000, 1000, 1000))
+    assert want[1] != int(plain[:, 0].min())        # really the flipped one
+
+    # (2) VispyRenderer protocol: update_cam_mat(K, left, right, bottom, top) + render_image(ob2cam_gl)
+    class Vispy:
+        def update_cam_mat(self, K, left, right, bottom, top):
+            self.args = (left, right, bottom, top)
+
+        def render_image(self, ob2cam_gl):
+            self.pose = ob2cam_gl
+            return Fx.synthetic_render(1, 0.75)
+    v = Vispy()
+    trk.renderer = v
+    rgbA, depthA = trk.render_window(P)
+    assert v.args == (want[0], want[2], want[3], want[1])
+    assert np.allclose(v.pose, np.diag([1.0, -1.0, -1.0, 1.0]) @ P) and rgbA.shape == (176, 176, 3)
+
+    # (3) full-frame renderer (offscreen_renderer.Renderer style): render([pose]) -> rgb, depth in metres;
+    #     cropped with the PLAIN bbox exactly as crop_bbox would (predict.py:209-213)
+    class Full:
+        full_frame = True
+
+        def render(self, poses):
+            rgb, depth = Fx.synthetic_frame(77)
+            self.rgb, self.depth_m = rgb, depth.astype(np.float64) / 1000.0
+            return self.rgb, self.depth_m
+    f = Full()
+    trk.renderer = f
+    rgbA, depthA = trk.render_window(P)
+    o_rgb, o_depth = O.crop_bbox(f.rgb, (f.depth_m * 1000).astype(np.uint16), plain, (176, 176))
+    assert (rgbA == o_rgb).all() and (depthA == o_depth).all() and depthA.dtype == np.uint16
+    trk.renderer = _Stub()
+
+
+def test_samples_beyond_capacity_and_depth_dtypes(se3, tracker):
+    trk, _ = tracker
+    P = Fx.pose(3)
+    rgb, depth = Fx.synthetic_frame(31)
+    trk.renderer = _Stub()
+    ref = trk.on_track(P, rgb, depth, samples=1)
+    for s in (4, 9, 64):                      # max_samples = 4: identical hypotheses, clamped, never overruns
+        trk.renderer = _Stub()
+        assert (trk.on_track(P, rgb, depth, samples=s) == ref).all()
+    # the raw ABI refuses to run past the context's input buffer
+    crop = dict(rgb=torch.from_numpy(rgb).cuda(), depth=torch.from_numpy(depth.view(np.int16)).cuda(),
+                window=(0, 0, 176, 176), z_offset_mm=800.0, stats=1)
+    with pytest.raises(se3._lib.Se3tnError):
+        trk.engine.preprocess([crop] * 5, trk.engine.input_buffer_ptr(1))
+    # wider depth dtypes are converted (as the reference's .astype(np.uint16)), not byte-reinterpreted
+    for dt in (np.int32, np.float32, np.float64, np.int64):
+        trk.renderer = _Stub()
+        assert (trk.on_track(P, rgb, depth.astype(dt)) == ref).all(), dt
+    with pytest.raises(ValueError):
+        trk.on_track(P, rgb, depth[:-1])
