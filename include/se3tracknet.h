@@ -173,6 +173,11 @@ int se3tn_pose_update_host(const double poseA[16], const float trans[3], const f
  * "ab" "ab_t" [n,24,24,256], "head" "head_t" [n,13,13,1024] (0-511 trans, 512-1023 rot).
  * dims = {H, W, C} as stored (borders included). */
 int se3tn_debug_buffer(se3tn_ctx* ctx, const char* name, const float** ptr, int32_t dims[3]);
+/* The fused Winograd blocks (batches of n >= the se3tn_set_winograd threshold) keep the activation between a
+ * residual block's two convolutions in LDS and reduce the heads' last activation in registers: "ab_t", "head_t"
+ * and "head" are then NOT written.  on != 0 makes those kernels store them as well (tests, feature inspection);
+ * results are bit-identical either way. */
+int se3tn_keep_intermediates(se3tn_ctx* ctx, int on);
 /* stream-ordered device-to-device copy (lets a ctypes host wrap the raw pointers above into its
  * own tensors without a second HIP binding) */
 int se3tn_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);

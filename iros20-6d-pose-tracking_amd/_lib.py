@@ -51,6 +51,7 @@ _SIGS = {
     "se3tn_set_winograd": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "se3tn_get_winograd": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "se3tn_overflow": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "se3tn_keep_intermediates": (C.c_int, [C.c_void_p, C.c_int]),
     "se3tn_set_normalizers": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "se3tn_preprocess": (C.c_int, [C.c_void_p, C.POINTER(Crop), C.c_int, C.c_void_p, C.c_void_p]),
     "se3tn_crop_raw": (C.c_int, [C.c_void_p, C.POINTER(Crop), C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -61,6 +61,8 @@ struct se3tn_ctx {
                                                 // in-place residual update cannot change format)
   const float* head_final = nullptr;            // what the tail of the last infer read
   float* logits = nullptr;                      // [mb,6]
+  float* fcpart = nullptr;                      // [mb,2,8,3] partial FC dot products of the fused Winograd tail
+  bool keep_intermediates = false;              // se3tn_keep_intermediates: fused blocks also store ab_t / head_t / head
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
   size_t part_bytes = 0;
   // Winograd F(m x m,3x3) path (wino_mfma.hip) of convAB2.* and trans|rot conv2.* at n >= wino_min_batch
@@ -169,7 +171,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
         {&c->ab, padded(S3, 256), true},       {&c->ab_t, padded(S3, 256), true},
         {&c->head, padded(S4, 1024), true},    {&c->head_t, padded(S4, 1024), true},
         {&c->head_f, padded(S4, 1024), true},
-        {&c->logits, mb * 6, true}};
+        {&c->logits, mb * 6, true},           {&c->fcpart, mb * 48, true}};
     for (auto& b : bufs) {
       e = hipMalloc((void**)b.p, b.words * sizeof(float));
       if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(workspace)"); }
@@ -197,7 +199,7 @@ void se3tn_destroy(se3tn_ctx* c) {
   if (!c) return;
   if (c->device >= 0) {
     float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
-                     c->head_t, c->head_f, c->logits, c->part, c->blob_owned, c->wino_v, c->wino_m,
+                     c->head_t, c->head_f, c->logits, c->fcpart, c->part, c->blob_owned, c->wino_v, c->wino_m,
                      c->wino_u[0], c->wino_u[1], c->wino_u[2], c->wino_u[3]};
     for (float* b : bufs)
       if (b) (void)hipFree(b);
@@ -297,6 +299,12 @@ int se3tn_set_precision(se3tn_ctx* c, int mode) {
   return SE3TN_OK;
 }
 
+int se3tn_keep_intermediates(se3tn_ctx* c, int on) {
+  if (!c) return fail(SE3TN_E_ARG, "null ctx");
+  c->keep_intermediates = on != 0;
+  return SE3TN_OK;
+}
+
 int se3tn_overflow(se3tn_ctx* c, int* flag) {
   if (!c || c->device < 0 || !flag) return fail(SE3TN_E_ARG, "se3tn_overflow: bad argument");
   HIPCHK(hipMemcpy(flag, c->overflow, sizeof(int), hipMemcpyDeviceToHost));
@@ -378,7 +386,7 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
   GraphKey key;
   std::memset(&key, 0, sizeof(key));
   key.A = A; key.B = B; key.trans = trans; key.rot = rot; key.poseA = poseA; key.poseB = poseB; key.blob = c->blob;
-  key.n = n; key.layout = layout; key.prec = c->prec; key.wino = c->wino_min_batch * 8 + c->wino_tile; key.tn = c->tn; key.rn = c->rn;
+  key.n = n; key.layout = layout; key.prec = c->prec; key.wino = (c->wino_min_batch * 8 + c->wino_tile) * 2 + (c->keep_intermediates ? 1 : 0); key.tn = c->tn; key.rn = c->rn;
   hipStream_t st = (hipStream_t)stream;
   for (auto& g : c->graphs) {
     if (!(g.key == key)) continue;
@@ -505,16 +513,51 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
   if ((rc = conv(L64_3, c->q64 + 64, 128, 0, nullptr, 0, 0, c->t64 + 64, 128, 0, S2, 1, 0, "conv64 B3.conv1"))) return rc;
   if ((rc = conv(L64_4, c->t64 + 64, 128, 0, c->q64 + 64, 128, 0, c->q64 + 64, 128, 0, S2, 1, 1, "conv64 B3.conv2"))) return rc;
   if ((rc = conv(LAB1, c->q64, 128, 0, nullptr, 0, 0, c->ab, 256, 0, S2, 2, 2, "convAB1 s2"))) return rc;
-  if ((rc = conv(LAB2_1, c->ab, 256, 0, nullptr, 0, 0, c->ab_t, 256, 0, S3, 1, 0, "convAB2.conv1"))) return rc;
-  if ((rc = conv(LAB2_2, c->ab_t, 256, 0, c->ab, 256, 0, c->ab, 256, 0, S3, 1, 1, "convAB2.conv2"))) return rc;
+  // ResnetBasicBlocks of 256 / 512 channels: at n >= wino_min_batch with F(4x4) the whole block runs through
+  // launch_wino_block (conv1's out-transform fused with conv2's in-transform; the heads' last out-transform fused
+  // with avg-pool + FC + tanh); otherwise conv by conv (direct / split-K / F(2x2) kernels)
+  const bool wino_block = !fast && c->wino_min_batch > 0 && n >= c->wino_min_batch && c->wino_v && c->wino_tile == 4;
+  struct MarkCtx { se3tn_ctx* c; hipStream_t st; const char* name; };
+  auto mark_fn = [](void* p) -> int { MarkCtx* m = (MarkCtx*)p; return prof_mark(m->c, m->st, m->name, true); };
+  auto block = [&](ConvId id1, ConvId id2, float* io, float* mid, int ld, int gs, int hin, const TailArgs* tl,
+                   const char* name1, const char* name2) -> int {
+    const Conv3& s = conv_specs()[id1];
+    WinoArgs w{};
+    w.in = io; w.U = c->wino_u[wino_slot(id1)]; w.bias = W + L.conv_b[id1]; w.res = nullptr; w.out = mid;
+    w.V = c->wino_v; w.Mw = c->wino_m;
+    w.in_ld = ld; w.res_ld = ld; w.out_ld = ld;
+    w.m = 4; w.nf = 36;
+    w.H = hin; w.W = hin; w.th = (hin + 3) / 4; w.tw = w.th;
+    w.n = n; w.T = n * w.th * w.tw;
+    w.C = s.cin; w.Cout = s.cout; w.groups = s.groups;
+    w.in_gs = gs; w.res_gs = gs; w.out_gs = gs; w.bias_gs = s.cout;
+    w.u_gs = (long long)w.nf * s.cin * s.cout;
+    MarkCtx mc{c, st, name1};
+    hipError_t e = launch_wino_block(w, c->wino_u[wino_slot(id2)], W + L.conv_b[id2], io, c->keep_intermediates ? 1 : 0,
+                                     (tl && c->keep_intermediates) ? io : nullptr, tl, st, mark_fn, &mc);
+    if (e != hipSuccess) return hipfail(e, name2);
+    return prof_mark(c, st, name2, true);
+  };
+  if (wino_block) {
+    if ((rc = block(LAB2_1, LAB2_2, c->ab, c->ab_t, 256, 0, S3, nullptr, "convAB2.conv1", "convAB2.conv2"))) return rc;
+  } else {
+    if ((rc = conv(LAB2_1, c->ab, 256, 0, nullptr, 0, 0, c->ab_t, 256, 0, S3, 1, 0, "convAB2.conv1"))) return rc;
+    if ((rc = conv(LAB2_2, c->ab_t, 256, 0, c->ab, 256, 0, c->ab, 256, 0, S3, 1, 1, "convAB2.conv2"))) return rc;
+  }
   if ((rc = conv(LH1, c->ab, 256, 0, nullptr, 0, 0, c->head, 1024, 0, S3, 2, 2, "trans|rot conv1 s2"))) return rc;
-  if ((rc = conv(LH2_1, c->head, 1024, 512, nullptr, 0, 0, c->head_t, 1024, 512, S4, 1, 0, "trans|rot conv2.conv1"))) return rc;
-  float* head_out = fast ? c->head_f : c->head;
-  if ((rc = conv(LH2_2, c->head_t, 1024, 512, c->head, 1024, 512, head_out, 1024, 512, S4, 1, 1, "trans|rot conv2.conv2"))) return rc;
-  c->head_final = head_out;
-
-  HIPCHK(launch_tail(head_out, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st));
-  HIPCHK((hipError_t)prof_mark(c, st, "tail avgpool+fc+tanh+pose", false));
+  if (wino_block) {
+    TailArgs tl{W + L.fc_w, W + L.fc_b, c->logits, c->fcpart, trans, rot, poseA, poseB, c->tn, c->rn};
+    if ((rc = block(LH2_1, LH2_2, c->head, c->head_t, 1024, 512, S4, &tl, "trans|rot conv2.conv1",
+                    "trans|rot conv2.conv2 + avgpool+fc+tanh+pose"))) return rc;
+    c->head_final = c->head;
+  } else {
+    if ((rc = conv(LH2_1, c->head, 1024, 512, nullptr, 0, 0, c->head_t, 1024, 512, S4, 1, 0, "trans|rot conv2.conv1"))) return rc;
+    float* head_out = fast ? c->head_f : c->head;
+    if ((rc = conv(LH2_2, c->head_t, 1024, 512, c->head, 1024, 512, head_out, 1024, 512, S4, 1, 1, "trans|rot conv2.conv2"))) return rc;
+    c->head_final = head_out;
+    HIPCHK(launch_tail(head_out, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st));
+    HIPCHK((hipError_t)prof_mark(c, st, "tail avgpool+fc+tanh+pose", false));
+  }
   if (c->prof) c->slot_launches[slot] = c->n_launch;
   return SE3TN_OK;
 }

@@ -44,9 +44,11 @@ namespace se3tn {
 
 // shared epilogue: lane holds pixel l31 x couts {8q + 4hh + 0..3} of each 32x32 tile.
 // MM_F16X3 accumulators carry the per-cout power-of-two weight scale: acc * wscale[c] first.
+// rpre != nullptr: the float32 residual values were loaded ahead of time (same [i][j][q] order)
 template <int PT, int CT, int EPI, int MM, int OUTF, int RESF>
 __device__ __forceinline__ void store_tiles(const ConvArgs& a, int g, const f32x16 (&acc)[PT][CT],
-                                            const int (&opix)[PT], const bool (&ok)[PT], int cbase, int hh) {
+                                            const int (&opix)[PT], const bool (&ok)[PT], int cbase, int hh,
+                                            const float4* rpre = nullptr) {
   const float* __restrict__ bias = a.bias + (size_t)g * a.bias_gs;
   const float* __restrict__ wsc = (MM == MM_F16X3) ? a.wscale + (size_t)g * a.bias_gs : nullptr;
   const float* __restrict__ res = (EPI == 1) ? a.res + (size_t)g * a.res_gs : nullptr;
@@ -68,9 +70,12 @@ __device__ __forceinline__ void store_tiles(const ConvArgs& a, int g, const f32x
         }
         const float4 b = *reinterpret_cast<const float4*>(bias + c);
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == 1)
-          r = (RESF == FMT_SPLIT) ? load_split4(res, (size_t)opix[i], a.res_ld, c)
-                                  : *reinterpret_cast<const float4*>(res + (size_t)opix[i] * a.res_ld + c);
+        if (EPI == 1) {
+          if (rpre) r = rpre[(i * CT + j) * 4 + q];
+          else
+            r = (RESF == FMT_SPLIT) ? load_split4(res, (size_t)opix[i], a.res_ld, c)
+                                    : *reinterpret_cast<const float4*>(res + (size_t)opix[i] * a.res_ld + c);
+        }
         v = apply_epilogue<EPI>(v, b, r);
         if (OUTF == FMT_SPLIT) bad |= store_split4(out, (size_t)opix[i], a.out_ld, c, v);
         else *reinterpret_cast<float4*>(out + (size_t)opix[i] * a.out_ld + c) = v;
@@ -196,9 +201,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_slab_kernel(const ConvArgs a) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // residual + ReLU epilogue of the short-K (64-channel) tiles: the residual values are fetched while the last
+    // chunk's MFMAs run instead of after them (an L2 / HBM round trip per tile otherwise sits in the epilogue)
+    constexpr bool PREFETCH_RES = (EPI == 1 && RESF == FMT_F32 && PT * CT <= 2);
+    float4 rpre[PREFETCH_RES ? PT * CT * 4 : 1];
+
     int kt = 0;
     for (int ch = 0; ch < NCH; ++ch) {
       const int sb = ch & 1;
+      if (PREFETCH_RES && ch == NCH - 1) {
+        const float* __restrict__ res_ = a.res + (size_t)g * a.res_gs;
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+          for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              rpre[(i * CT + j) * 4 + q] = *reinterpret_cast<const float4*>(
+                  res_ + (size_t)opix[i] * a.res_ld + n0 + wn * CT * 32 + j * 32 + q * 8 + hh * 4);
+      }
       for (int tap = 0; tap < 9; ++tap, ++kt) {
         const int wb = kt & 1;
         // next K-step's weights, and this wave's share of the next slab (next chunk, or chunk 0 of the
@@ -243,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_slab_kernel(const ConvArgs a) 
         if (kt + 1 < NCH * 9 || more) wait_dma_and_barrier();
       }
     }
-    store_tiles<PT, CT, EPI, MM, OUTF, RESF>(a, g, acc, opix, ok, n0 + wn * CT * 32, hh);
+    store_tiles<PT, CT, EPI, MM, OUTF, RESF>(a, g, acc, opix, ok, n0 + wn * CT * 32, hh, PREFETCH_RES ? rpre : nullptr);
     if (!more) break;
     tile = tnext;
     lo = nlo;

@@ -148,8 +148,21 @@ struct WinoArgs {
   long long u_gs;     // floats per group of U
 };
 
+// outputs of the fused out-transform + avg-pool + FC + tanh (wino_tail_kernel)
+struct TailArgs {
+  const float* fc_w;  // [2 heads][3][512]
+  const float* fc_b;  // [2][4]
+  float* logits;      // [n,6] pre-tanh
+  float* fcpart;      // [n][2 heads][8 channel slices][3] partial FC dot products
+  float* trans;       // [n,3] or nullptr
+  float* rot;         // [n,3] or nullptr
+  const double* poseA;  // [n,16] or nullptr
+  double* poseB;
+  double tn, rn;
+};
+
 struct CropArgs {  // one launch handles up to MAX crops
-  static constexpr int MAX = 24;
+  static constexpr int MAX = 64;  // 64 x 48 B + constants = 3.3 KB of kernel arguments (< 4 KB)
   se3tn_crop c[MAX];
   double mean[8], stdv[8];
   float* out;   // plain [n,176,176,4], or (padded != 0) the interior of [n,182,182,4]
@@ -189,6 +202,10 @@ hipError_t launch_conv3x3(const ConvArgs& a, int cin, int cout, int stride, int 
 // batched MFMA GEMMs + output transform with the conv epilogue (epi 0 | 1)
 hipError_t launch_wino_weights(const float* packed, float* U, int cin, int cout, int m, hipStream_t st);
 hipError_t launch_wino_conv(const WinoArgs& a, int epi, hipStream_t st);
+// a whole residual block on the Winograd F(4x4) path with the fused mid / tail transforms (wino_mfma.hip);
+// mark_after_mid: optional profiling hook called between conv1 and conv2 (returns non-zero on error)
+hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* bias2, float* out2, int keep_mid,
+                             float* keep_out2, const TailArgs* tl, hipStream_t st, int mark_after_mid(void*), void* mark_ctx);
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,
                        double rn, int n, hipStream_t st);

@@ -25,6 +25,17 @@
 // after the four layers that use it the logits move by ~1e-6, two orders inside the 1e-4 tolerance
 // (tests/test_gpu_parity.py::test_winograd_*).
 #include "mfma_common.h"
+#include "pose_device.h"
+
+#ifndef WINO4_VEC
+#define WINO4_VEC 2  // channels per thread of the F(4x4) transform kernels (2: 8-byte, 4: 16-byte accesses; measured equal)
+#endif
+#ifndef WINO_MID_CS_AB
+#define WINO_MID_CS_AB 32  // channels per workgroup of wino_mid_kernel on the 22 x 22 maps (LDS 26 x 26 x CS floats)
+#endif
+#ifndef WINO_MID_CS_H
+#define WINO_MID_CS_H 32   // ... on the 11 x 11 maps (LDS 14 x 14 x CS floats)
+#endif
 
 namespace se3tn {
 
@@ -333,6 +344,239 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
   }
 }
 
+
+// =================================================================================================
+// Block-level fusions of the F(4x4) path (a ResnetBasicBlock = conv1+BN+ReLU, conv2+BN, +x, ReLU;
+// network_modules.py:103-120).  Both remove a full write + read of an activation tensor between two
+// HBM-bound transform passes:
+//   wino_mid_kernel   out-transform of conv1 (A^T M A + bias, ReLU) and in-transform of conv2 (B^T d B) in one
+//                     pass: one workgroup = one image x CS channels, the 4TH x 4TH activation lives in LDS
+//                     (zero border included) between the two phases; the activation tensor itself is only
+//                     written on request (keep != nullptr: tests / se3tn_debug_buffer);
+//   wino_tail_kernel  out-transform of the heads' last conv (+ bias + residual, ReLU) with AdaptiveAvgPool2d(1),
+//                     Linear(512,3) and Tanh (se3_tracknet.py:72-73,77-78,100-109): one workgroup = one image x
+//                     one head, the 11 x 11 x 512 activation is reduced in registers and never stored
+//                     (again unless asked for).  The float64 pose update follows in pose_update_kernel.
+// =================================================================================================
+template <int TH, int CS>
+__global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_mid_kernel(const WinoArgs a, float* __restrict__ keep) {
+  constexpr int M = 4, N = 6, HP = 4 * TH + 2, NT = TH * TH, CP = CS / 2, ITEMS = NT * CP;
+  extern __shared__ __attribute__((aligned(16))) float act[];  // [HP][HP][CS], padded coordinates
+  const int n = blockIdx.x, c0 = blockIdx.y * CS, g = blockIdx.z;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < HP * HP * CS / 4; i += blockDim.x) reinterpret_cast<float4*>(act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int tile = tid / CP, cp = tid - tile * CP;
+  const int ty = tile / TH, tx = tile - ty * TH;
+  const bool active = tid < ITEMS;
+  const int t = n * NT + tile;
+  const int Hp = a.H + 2, Wp = a.W + 2;
+  if (active) {
+    const float* __restrict__ src = a.Mw + ((size_t)g * a.nf * a.T + t) * a.Cout + c0 + cp * 2;
+    const size_t fs = (size_t)a.T * a.Cout;
+    float u[M][N][2];
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+      float m[N][2];
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const float2 v = *reinterpret_cast<const float2*>(src + (size_t)(N * r + s) * fs);
+        m[r][0] = v.x; m[r][1] = v.y;
+      }
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float acc = 0.f;
+          bool first = true;
+#pragma unroll
+          for (int r = 0; r < N; ++r) axpy(acc, wino_at<M>(i, r), m[r][e], first);
+          u[i][s][e] = acc;
+        }
+    }
+    const float2 b = *reinterpret_cast<const float2*>(a.bias + (size_t)g * a.bias_gs + c0 + cp * 2);
+    float* __restrict__ kp = keep ? keep + (size_t)g * a.out_gs + c0 + cp * 2 : nullptr;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const int oy = M * ty + i, ox = M * tx + j;
+        if (oy >= a.H || ox >= a.W) continue;
+        float o[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float acc = 0.f;
+          bool first = true;
+#pragma unroll
+          for (int s = 0; s < N; ++s) axpy(acc, wino_at<M>(j, s), u[i][s][e], first);
+          o[e] = fmaxf(acc + (e ? b.y : b.x), 0.f);
+        }
+        *reinterpret_cast<float2*>(act + ((oy + 1) * HP + ox + 1) * CS + cp * 2) = make_float2(o[0], o[1]);
+        if (kp) *reinterpret_cast<float2*>(kp + (size_t)((n * Hp + oy + 1) * Wp + ox + 1) * a.out_ld) = make_float2(o[0], o[1]);
+      }
+  }
+  __syncthreads();
+  if (active) {
+    float bt[N][N][2];  // B^T d, one column s at a time
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+      float d[N][2];
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const float2 v = *reinterpret_cast<const float2*>(act + ((M * ty + r) * HP + M * tx + s) * CS + cp * 2);
+        d[r][0] = v.x; d[r][1] = v.y;
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float acc = 0.f;
+          bool first = true;
+#pragma unroll
+          for (int r = 0; r < N; ++r) axpy(acc, wino_bt<M>(i, r), d[r][e], first);
+          bt[i][s][e] = acc;
+        }
+    }
+    float* __restrict__ dst = a.V + ((size_t)g * a.nf * a.T + t) * a.C + c0 + cp * 2;
+    const size_t fs = (size_t)a.T * a.C;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        float o[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float acc = 0.f;
+          bool first = true;
+#pragma unroll
+          for (int s = 0; s < N; ++s) axpy(acc, wino_bt<M>(j, s), bt[i][s][e], first);
+          o[e] = acc;
+        }
+        *reinterpret_cast<float2*>(dst + (size_t)(N * i + j) * fs) = make_float2(o[0], o[1]);
+      }
+  }
+}
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// grid (n, 512 / CS channel slices, 2 heads); thread = (tile, channel pair) like wino_output_kernel, so the pass has the
+// same parallelism; the per-channel sums over the map are reduced through LDS in a fixed order, each workgroup
+// contributes the partial dot products of its CS channels with the head's three FC rows:
+// fcpart[n][head][slice][3].  fc_finish_kernel adds the slices (fixed order), the bias, applies tanh and the pose update.
+template <int TH, int CS>
+__global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_tail_kernel(const WinoArgs a, float* __restrict__ keep,
+                                                                                         const float* __restrict__ fc_w,
+                                                                                         float* __restrict__ fcpart) {
+  constexpr int M = 4, N = 6, NT = TH * TH, CP = CS / 2, ITEMS = NT * CP;
+  static_assert(CP == 32, "the FC partials are reduced inside one half-wave");
+  __shared__ float red[NT][CP][2];
+  const int n = blockIdx.x, sl = blockIdx.y, g = blockIdx.z, tid = threadIdx.x;
+  const int tile = tid / CP, cp = tid - tile * CP;
+  const int c = sl * CS + cp * 2;   // channel within the head
+  const int Hp = a.H + 2, Wp = a.W + 2;
+  if (tid < ITEMS) {
+    const int ty = tile / TH, tx = tile - ty * TH;
+    const size_t fs = (size_t)a.T * a.Cout;
+    const float* __restrict__ src = a.Mw + ((size_t)g * a.nf * a.T + n * NT + tile) * a.Cout + c;
+    const float* __restrict__ res = a.res + (size_t)g * a.res_gs + c;
+    float* __restrict__ kp = keep ? keep + (size_t)g * a.out_gs + c : nullptr;
+    const float2 b = *reinterpret_cast<const float2*>(a.bias + (size_t)g * a.bias_gs + c);
+    float u[M][N][2];
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+      float m[N][2];
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const float2 v = *reinterpret_cast<const float2*>(src + (size_t)(N * r + s) * fs);
+        m[r][0] = v.x; m[r][1] = v.y;
+      }
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float acc = 0.f;
+          bool first = true;
+#pragma unroll
+          for (int r = 0; r < N; ++r) axpy(acc, wino_at<M>(i, r), m[r][e], first);
+          u[i][s][e] = acc;
+        }
+    }
+    float sum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const int oy = M * ty + i, ox = M * tx + j;
+        if (oy >= a.H || ox >= a.W) continue;
+        const size_t pix = (size_t)((n * Hp + oy + 1) * Wp + ox + 1);
+        const float2 r = *reinterpret_cast<const float2*>(res + pix * a.res_ld);
+        float o[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float acc = 0.f;
+          bool first = true;
+#pragma unroll
+          for (int s = 0; s < N; ++s) axpy(acc, wino_at<M>(j, s), u[i][s][e], first);
+          o[e] = fmaxf(acc + (e ? b.y : b.x) + (e ? r.y : r.x), 0.f);
+          sum[e] += o[e];
+        }
+        if (kp) *reinterpret_cast<float2*>(kp + pix * a.out_ld) = make_float2(o[0], o[1]);
+      }
+    red[tile][cp][0] = sum[0];
+    red[tile][cp][1] = sum[1];
+  }
+  __syncthreads();
+  if (tid < CP) {   // lanes 0-31 of wave 0: channel pair tid
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { s0 += red[t][tid][0]; s1 += red[t][tid][1]; }
+    const float inv = (float)(a.H * a.W);
+    s0 /= inv; s1 /= inv;
+    float acc[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const float2 w = *reinterpret_cast<const float2*>(fc_w + (g * 3 + o) * 512 + sl * CS + tid * 2);
+      float v = s0 * w.x + s1 * w.y;
+#pragma unroll
+      for (int sh = 16; sh > 0; sh >>= 1) v += __shfl_xor(v, sh, 64);   // lanes 0-31 only exchange among themselves
+      acc[o] = v;
+    }
+    if (tid == 0) {
+      float* dst = fcpart + ((size_t)(n * 2 + g) * (512 / CS) + sl) * 3;
+      dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2];
+    }
+  }
+}
+
+// 6 threads per pair (one per output): logit = sum of the slices' partial dot products (fixed order) + bias; tanh;
+// the pair's first thread then composes the pose.  10 pairs per 64-thread workgroup.
+__global__ __launch_bounds__(64) void fc_finish_kernel(const float* __restrict__ fcpart, int slices, const TailArgs tl,
+                                                        const double* __restrict__ poseA, double* __restrict__ poseB, double tn,
+                                                        double rn, int n) {
+  __shared__ float y[60];
+  const int t = threadIdx.x, li = t / 6, k = t - li * 6;
+  const int i = blockIdx.x * 10 + li;
+  const bool ok = t < 60 && i < n;
+  if (ok) {
+    const int g = k / 3, o = k - g * 3;
+    const float* p = fcpart + ((size_t)(i * 2 + g) * slices) * 3 + o;
+    float lg = 0.f;
+    for (int s = 0; s < slices; ++s) lg += p[s * 3];
+    lg += tl.fc_b[g * 4 + o];
+    const float v = tanhf(lg);
+    y[t] = v;
+    tl.logits[i * 6 + k] = lg;
+    float* dst = g == 0 ? tl.trans : tl.rot;
+    if (dst) dst[i * 3 + o] = v;
+  }
+  __syncthreads();
+  if (ok && k == 0 && poseA) pose_compose(y + li * 6, poseA + (size_t)i * 16, poseB + (size_t)i * 16, tn, rn);
+}
+
 // ---- launchers ---------------------------------------------------------------------------------
 hipError_t launch_wino_weights(const float* packed, float* U, int cin, int cout, int m, hipStream_t st) {
   const int total = cin * cout;
@@ -382,10 +626,63 @@ static hipError_t launch_transformed(const WinoArgs& a, int epi, hipStream_t st)
   return hipGetLastError();
 }
 
+
+// One ResnetBasicBlock on the F(4x4) path: in-transform, GEMM(U1), [out|in] mid transform, GEMM(U2), then either
+// the out-transform with the residual epilogue or (tl != nullptr, the heads' last block) the fused
+// out-transform + avg-pool + FC + tanh.  c1 describes conv1 (in = block input, out = the intermediate activation
+// buffer, only written if keep_mid); conv2 reads the same V / Mw workspaces, residual = c1.in, output = out2.
+template <int TH, int CS>
+static hipError_t launch_mid(const WinoArgs& a, float* keep, hipStream_t st) {
+  constexpr int HP = 4 * TH + 2, THREADS = ((TH * TH * (CS / 2) + 63) / 64) * 64;
+  constexpr size_t lds = (size_t)HP * HP * CS * sizeof(float);
+  static PerDeviceOnce attr;
+  auto kern = wino_mid_kernel<TH, CS>;
+  bool* done = attr.current();
+  if (!done || !*done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (done) *done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.n, a.C / CS, a.groups), dim3(THREADS), lds, st, a, keep);
+  return hipGetLastError();
+}
+
+hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* bias2, float* out2, int keep_mid,
+                             float* keep_out2, const TailArgs* tl, hipStream_t st, int mark_after_mid(void*), void* mark_ctx) {
+  if (c1.m != 4 || c1.nf != 36 || c1.C != c1.Cout || (c1.C != 256 && c1.C != 512)) return hipErrorInvalidValue;
+  if (!((c1.th == 6 && c1.C == 256) || (c1.th == 3 && c1.C == 512)) || c1.tw != c1.th) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((wino_input_kernel<4, WINO4_VEC>), dim3((c1.T * (c1.C / WINO4_VEC) + 255) / 256, c1.groups), dim3(256), 0, st, c1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = c1.C == 256 ? launch_gemm_auto<256>(c1, st) : launch_gemm_auto<512>(c1, st);
+  if (e != hipSuccess) return e;
+  e = c1.th == 6 ? launch_mid<6, WINO_MID_CS_AB>(c1, keep_mid ? c1.out : nullptr, st)
+                 : launch_mid<3, WINO_MID_CS_H>(c1, keep_mid ? c1.out : nullptr, st);
+  if (e != hipSuccess) return e;
+  if (mark_after_mid && mark_after_mid(mark_ctx)) return hipErrorUnknown;
+  WinoArgs c2 = c1;
+  c2.U = U2; c2.bias = bias2; c2.res = c1.in; c2.res_ld = c1.in_ld; c2.res_gs = c1.in_gs; c2.out = out2;
+  e = c1.C == 256 ? launch_gemm_auto<256>(c2, st) : launch_gemm_auto<512>(c2, st);
+  if (e != hipSuccess) return e;
+  if (tl) {
+    if (c1.th != 3 || c1.groups != 2 || c1.Cout != 512) return hipErrorInvalidValue;
+    constexpr int CS = 64, THREADS = ((9 * (CS / 2) + 63) / 64) * 64;
+    hipLaunchKernelGGL((wino_tail_kernel<3, CS>), dim3(c1.n, 512 / CS, 2), dim3(THREADS), 0, st, c2, keep_out2, tl->fc_w, tl->fcpart);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fc_finish_kernel, dim3((c1.n + 9) / 10), dim3(64), 0, st, tl->fcpart, 512 / CS, *tl, tl->poseA, tl->poseB,
+                       tl->tn, tl->rn, c1.n);
+  } else {
+    const dim3 og((c2.T * (c2.Cout / WINO4_VEC) + 255) / 256, c2.groups);
+    hipLaunchKernelGGL((wino_output_kernel<4, WINO4_VEC, 1>), og, dim3(256), 0, st, c2);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_wino_conv(const WinoArgs& a, int epi, hipStream_t st) {
   if ((a.C != 256 && a.C != 512) || a.Cout % 128 != 0 || (epi != 0 && epi != 1)) return hipErrorInvalidValue;
   if (a.m == 2 && a.nf == 16) return launch_transformed<2, 4>(a, epi, st);
-  if (a.m == 4 && a.nf == 36) return launch_transformed<4, 2>(a, epi, st);
+  if (a.m == 4 && a.nf == 36) return launch_transformed<4, WINO4_VEC>(a, epi, st);
   return hipErrorInvalidValue;
 }
 

@@ -121,6 +121,11 @@ class Engine:
         check(self.lib.se3tn_get_winograd(self._h, C.byref(mb), C.byref(t)), "se3tn_get_winograd")
         return mb.value, t.value
 
+    def keep_intermediates(self, on=True):
+        """Make the fused Winograd blocks also store the activations they otherwise keep on chip ("ab_t", "head_t",
+        "head" of debug_buffer); results are bit-identical either way."""
+        check(self.lib.se3tn_keep_intermediates(self._h, 1 if on else 0), "se3tn_keep_intermediates")
+
     def overflow(self):
         """True if a split-row store left the f16 range since the last call (synchronises)."""
         f = C.c_int(0)

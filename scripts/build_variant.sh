@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage: build_variant.sh <name> "<extra hipcc flags>"   -> /root/repo/variants/lib_<name>.so
+set -e
+NAME=$1; FLAGS=$2
+SRC=/root/repo/iros20-6d-pose-tracking_amd/csrc
+OUT=/tmp/variants/$NAME
+mkdir -p $OUT /root/repo/variants
+cd $SRC
+for f in api.cpp weights.cpp; do
+  [ -f $SRC/build/$f.o ] && cp $SRC/build/$f.o $OUT/$f.o
+done
+for f in conv3x3_mfma.hip wino_mfma.hip stem7x7_mfma.hip kernels_misc.hip raster.hip; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result $FLAGS -c $f -o $OUT/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o /root/repo/variants/lib_$NAME.so $OUT/*.o
+ls -la /root/repo/variants/lib_$NAME.so

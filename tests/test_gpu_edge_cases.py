@@ -88,19 +88,19 @@ def test_preprocess_odd_frame_and_all_invalid_depth(se3):
 
 
 def test_more_crops_than_one_launch_holds(se3):
-    """se3tn_preprocess chunks the descriptors into kernel-argument blocks of 24."""
+    """se3tn_preprocess chunks the descriptors into kernel-argument blocks of 64 (CropArgs::MAX)."""
     rng = np.random.default_rng(2)
     rgb = torch.from_numpy(rng.integers(0, 256, (200, 260, 3), dtype=np.uint8)).cuda()
     depth = torch.from_numpy(rng.integers(300, 1500, (200, 260)).astype(np.uint16).view(np.int16)).cuda()
     eng = se3.Engine(0, 64)
     mean, std = Fx.mean_std(0)
     eng.set_normalization(mean, std)
-    n = 53
+    n = 133
     out = torch.empty((n, 176, 176, 4), device="cuda")
-    wins = [(int(i * 3 - 20), int(10 - i), int(i * 3 + 150), int(180 - i)) for i in range(n)]
+    wins = [(int(i * 3 - 20), int(10 - i % 60), int(i * 3 + 150), int(180 - i % 60)) for i in range(n)]
     eng.preprocess([dict(rgb=rgb, depth=depth, window=w, z_offset_mm=600.0 + i, stats=i & 1) for i, w in enumerate(wins)], out)
     r, d = rgb.cpu().numpy(), depth.cpu().numpy().view(np.uint16)
-    for i in (0, 23, 24, 47, 48, 52):
+    for i in (0, 23, 24, 63, 64, 65, 127, 128, 132):
         want = _oracle_crop(r, d, wins[i], 600.0 + i, mean, std, i & 1)
         assert (out[i].permute(2, 0, 1).cpu().numpy() == want).all(), i
 

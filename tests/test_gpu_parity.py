@@ -151,6 +151,7 @@ def test_winograd_path_vs_direct_and_oracle(se3, golden_dir, tile):
     m.load_state_dict(sd)
     m.cuda(0).eval()
     eng = m.engine
+    eng.keep_intermediates(True)   # the fused F(4x4) blocks do not store ab_t / head_t / head otherwise
     g = np.load(os.path.join(golden_dir, "network_n3.npz"))
     A, B = Fx.net_inputs(1, 3)
     ref = O.forward(sd, A, B, intermediates=True)
@@ -268,6 +269,36 @@ def test_batch64_every_pair_vs_oracle_and_reference_golden(se3, model0, golden_d
         finally:
             leave()
     assert not torch.equal(logits[0], logits[1]) and not torch.equal(logits[1], logits[2])
+
+
+def test_fused_winograd_blocks_keep_intermediates_is_bit_neutral(se3, model0):
+    """The fused F(4x4) blocks (mid transform in LDS, tail reduced in registers) with and without the optional
+    activation stores: identical bits; with the stores the kept tensors equal what the unfused per-conv path
+    (F(2x2) selects it) would have left within Winograd rounding, and the zero borders stay zero."""
+    model, sd = model0
+    eng = model.engine
+    A, B = Fx.net_inputs(23, 16)
+    Ac, Bc = A.cuda(), B.cuda()
+    o0 = model(Ac, Bc)
+    l0, f0, t0 = eng.logits(16).clone(), o0["feature"].clone(), o0["trans"].clone()
+    eng.keep_intermediates(True)
+    try:
+        o1 = model(Ac, Bc)
+        assert torch.equal(eng.logits(16), l0) and torch.equal(o1["feature"], f0) and torch.equal(o1["trans"], t0)
+        head = _nchw(eng.debug_buffer("head", 16), 1)
+        head_t = _nchw(eng.debug_buffer("head_t", 16), 1)
+        ab_t = _nchw(eng.debug_buffer("ab_t", 16), 1)
+        ref = O.forward(sd, A[:2], B[:2], intermediates=True)
+        _close("kept trans_conv2", head[:2, :512], ref["trans_c2"], ACT_RTOL, 0, 6e-5)
+        _close("kept rot_conv2", head[:2, 512:], ref["rot_c2"], ACT_RTOL, 0, 6e-5)
+        assert float(head_t.abs().max()) > 0 and float(ab_t.abs().max()) > 0
+        # the logits are the FC of the mean of the kept activation
+        mean = head.mean(dim=(2, 3))
+        lg = torch.cat([mean[:, :512] @ sd["trans_out.0.weight"].T + sd["trans_out.0.bias"],
+                        mean[:, 512:] @ sd["rot_out.0.weight"].T + sd["rot_out.0.bias"]], 1)
+        _close("logits from kept head", l0.cpu(), lg, 0, 2e-6)
+    finally:
+        eng.keep_intermediates(False)
 
 
 def test_batch_permutation_equivariance_bitwise(se3, model0):
