@@ -157,6 +157,19 @@ void se3tn_mesh_destroy(se3tn_mesh* mesh);
 int se3tn_render(se3tn_ctx* ctx, se3tn_mesh* mesh, const double ob_in_cam[16], const double K[9],
                  const int32_t window[4], uint8_t* rgb, uint16_t* depth, void* stream);
 
+/* ---- live-camera front end: depth hole filling ---------------------------------------------------- */
+/* Utils.py:455-514 `fill_depth` as predict_ros.py:38-41 applies it to every depth frame before on_track:
+ *     depth = fill_depth(depth_mm / 1e3, max_depth, extrapolate, blur_type);  out_mm = (depth * 1000).astype(uint16)
+ * depth_mm: device uint16 [H,W] millimetres; out_mm: device uint16 [H,W] and / or out_m: device float32 [H,W] metres
+ * (either may be NULL).  blur: the reference's blur_type ('bilateral' is its default; anything else but 'gaussian'
+ * skips the blur).  The first call for a frame size larger than any before allocates the scratch images (the one
+ * exception to "no hidden hipMalloc"; call it once at start-up). */
+#define SE3TN_BLUR_NONE 0
+#define SE3TN_BLUR_BILATERAL 1
+#define SE3TN_BLUR_GAUSSIAN 2
+int se3tn_fill_depth(se3tn_ctx* ctx, const uint16_t* depth_mm, int H, int W, double max_depth_m, int extrapolate,
+                     int blur, uint16_t* out_mm, float* out_m, void* stream);
+
 /* ---- host-side pieces of the path (pure CPU, float64, as the reference computes them) ----- */
 /* Utils.py:302-316 compute_bbox with scale (1000,1000,1000): pose row-major 4x4 (metres), K
  * row-major 3x3, width in mm; out_vu[8] = 4 x (v,u) int32, np.round (half-to-even). */

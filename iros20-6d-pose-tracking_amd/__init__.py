@@ -12,8 +12,9 @@ from .tracker import Tracker
 from .utils import compute_bbox, crop_window
 from . import metrics, sequence
 from .renderer import HipRenderer
+from .live import LiveTracker, quaternion_from_matrix
 
 _lib.load()
 
 __all__ = ["Engine", "Se3TrackNet", "Tracker", "compute_bbox", "crop_window", "pack_crops", "pose_update_host", "NCHW", "NHWC",
-           "metrics", "sequence", "HipRenderer"]
+           "metrics", "sequence", "HipRenderer", "LiveTracker", "quaternion_from_matrix"]

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SE3TN_LIB") or os.path.join(_HERE, "libse3tracknet.so
 
 NCHW, NHWC = 0, 1
 PREC_F32, PREC_F16X3 = 0, 1
+BLUR_NONE, BLUR_BILATERAL, BLUR_GAUSSIAN = 0, 1, 2
 RES = 176
 
 
@@ -66,6 +67,8 @@ _SIGS = {
     "se3tn_mesh_destroy": (None, [C.c_void_p]),
     "se3tn_render": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "se3tn_fill_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
     "se3tn_compute_bbox": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
                                      C.POINTER(C.c_int32)]),
     "se3tn_pose_update_host": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -77,6 +77,8 @@ struct se3tn_ctx {
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
   int* overflow = nullptr;                      // device flag: a split-row store left the f16 range
   unsigned long long* zbuf = nullptr;           // rasteriser z-buffer keys [176*176]
+  float* fd_buf = nullptr;                      // se3tn_fill_depth scratch: 3 images + minmax[2] + lut[4098]
+  size_t fd_pixels = 0;
   bool use_graphs = false;                      // se3tn_enable_graphs
   std::vector<GraphEntry> graphs;
   double mean[8], stdv[8];
@@ -207,6 +209,7 @@ void se3tn_destroy(se3tn_ctx* c) {
       if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (c->overflow) (void)hipFree(c->overflow);
     if (c->zbuf) (void)hipFree(c->zbuf);
+    if (c->fd_buf) (void)hipFree(c->fd_buf);
     for (int s = 0; s < c->slots; ++s)
       for (auto& e : c->evs[s]) (void)hipEventDestroy(e);
   }
@@ -635,6 +638,29 @@ int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const 
   for (int r = 0; r < 3; ++r)
     a.light[r] = (float)(sgn[r] * (ob_in_cam[4 * r] * l[0] + ob_in_cam[4 * r + 1] * l[1] + ob_in_cam[4 * r + 2] * l[2]));
   HIPCHK(launch_raster(a, (hipStream_t)stream));
+  return SE3TN_OK;
+}
+
+int se3tn_fill_depth(se3tn_ctx* c, const uint16_t* depth_mm, int H, int W, double max_depth_m, int extrapolate, int blur,
+                     uint16_t* out_mm, float* out_m, void* stream) {
+  if (!c || c->device < 0 || !depth_mm || H < 1 || W < 1 || (!out_mm && !out_m) || blur < 0 || blur > 2)
+    return fail(SE3TN_E_ARG, "se3tn_fill_depth: bad argument");
+  const size_t px = (size_t)H * W;
+  if (px > c->fd_pixels) {   // start-up (or a larger camera): scratch images
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (c->fd_buf) HIPCHK(hipFree(c->fd_buf));
+    c->fd_buf = nullptr; c->fd_pixels = 0;
+    HIPCHK(hipMalloc((void**)&c->fd_buf, (3 * px + 2 + 4098 + 2) * sizeof(float)));
+    c->fd_pixels = px;
+  }
+  FillDepthArgs a{};
+  a.depth_mm = depth_mm; a.H = H; a.W = W; a.max_depth = max_depth_m; a.extrapolate = extrapolate; a.blur = blur;
+  a.sigma_color = 1.5; a.sigma_space = 2.0;   // Utils.py:505 cv2.bilateralFilter(depth, 5, 1.5, 2.0)
+  a.buf0 = c->fd_buf; a.buf1 = c->fd_buf + px; a.buf2 = c->fd_buf + 2 * px;
+  a.minmax = reinterpret_cast<unsigned*>(c->fd_buf + 3 * px);
+  a.lut = c->fd_buf + 3 * px + 2;
+  a.out_mm = out_mm; a.out_m = out_m;
+  HIPCHK(launch_fill_depth(a, (hipStream_t)stream));
   return SE3TN_OK;
 }
 

@@ -232,6 +232,22 @@ struct RasterArgs {
 };
 hipError_t launch_raster(const RasterArgs& a, hipStream_t st);
 
+// depth hole filling (depth_fill.hip)
+struct FillDepthArgs {
+  const uint16_t* depth_mm;  // [H,W]
+  int H, W;
+  double max_depth;          // metres
+  int extrapolate;
+  int blur;                  // SE3TN_BLUR_*
+  double sigma_color, sigma_space;
+  float *buf0, *buf1, *buf2; // [H,W] float32 scratch
+  unsigned* minmax;          // [2]
+  float* lut;                // [4098]
+  uint16_t* out_mm;          // [H,W] or nullptr
+  float* out_m;              // [H,W] or nullptr
+};
+hipError_t launch_fill_depth(const FillDepthArgs& a, hipStream_t st);
+
 // host-side packer (weights.cpp)
 struct HostTensor {
   const float* data;

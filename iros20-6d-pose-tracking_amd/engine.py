@@ -181,6 +181,26 @@ class Engine:
                                       _stream_ptr()), "se3tn_crop_raw")
         return out_rgb.cpu().numpy(), out_d.cpu().numpy().view(np.uint16)
 
+    def fill_depth(self, depth_mm, max_depth=2.0, extrapolate=False, blur_type="bilateral", return_metres=False):
+        """Utils.py:455-514 fill_depth as predict_ros.py:38-41 applies it: uint16 millimetre frame (numpy [H,W] or a
+        cuda int16/uint16 tensor) -> hole-filled uint16 millimetres (same container kind); return_metres=True also
+        returns the float32 metre image fill_depth itself returns."""
+        dev = "cuda:%d" % self.device
+        is_np = not torch.is_tensor(depth_mm)
+        d = torch.from_numpy(np.ascontiguousarray(depth_mm, dtype=np.uint16).view(np.int16)).to(dev) if is_np else depth_mm
+        assert d.is_cuda and d.element_size() == 2 and d.dim() == 2 and d.is_contiguous()
+        H, W = int(d.shape[0]), int(d.shape[1])
+        out = torch.empty((H, W), dtype=torch.int16, device=dev)
+        out_m = torch.empty((H, W), dtype=torch.float32, device=dev) if return_metres else None
+        blur = {"bilateral": _lib.BLUR_BILATERAL, "gaussian": _lib.BLUR_GAUSSIAN}.get(blur_type, _lib.BLUR_NONE)
+        check(self.lib.se3tn_fill_depth(self._h, C.c_void_p(d.data_ptr()), H, W, float(max_depth), 1 if extrapolate else 0, blur,
+                                        C.c_void_p(out.data_ptr()), C.c_void_p(out_m.data_ptr()) if return_metres else None,
+                                        _stream_ptr()), "se3tn_fill_depth")
+        if is_np:
+            mm = out.cpu().numpy().view(np.uint16)
+            return (mm, out_m.cpu().numpy()) if return_metres else mm
+        return (out, out_m) if return_metres else out
+
     def infer(self, A, B, n, layout=NCHW, trans=None, rot=None, poseA=None, poseB=None):
         def p(x):
             if x is None:
