@@ -157,6 +157,18 @@ void se3tn_mesh_destroy(se3tn_mesh* mesh);
 int se3tn_render(se3tn_ctx* ctx, se3tn_mesh* mesh, const double ob_in_cam[16], const double K[9],
                  const int32_t window[4], uint8_t* rgb, uint16_t* depth, void* stream);
 
+/* The reference's second renderer, offscreen_renderer.py:48-83 (pyrender; dataset_info['renderer'] == 'pyrenderer',
+ * predict.py:161-164, textured .obj models): a FULL W x H camera frame, ambient light only, depth = camera z.
+ * se3tn_mesh_set_texture attaches the material: per-vertex texture coordinates uv [V,2] (OBJ convention, v up),
+ * an RGB uint8 image [th,tw,3] (row 0 = top; NULL: the vertex colours are the base colour) and the mtl's Kd
+ * (NULL: 1,1,1); host pointers, copied; the mip pyramid is built here.  se3tn_render_frame writes device
+ * rgb uint8 [H,W,3] and depth uint16 [H,W] millimetres ((depth * 1000).astype(uint16), predict.py:211); feed
+ * them to se3tn_preprocess / se3tn_crop_raw with the plain compute_bbox window exactly like a camera frame
+ * (predict.py:209-213).  The first call for a larger frame allocates its z-buffer. */
+int se3tn_mesh_set_texture(se3tn_mesh* mesh, const float* uv, const uint8_t* rgb, int tw, int th, const float kd[3]);
+int se3tn_render_frame(se3tn_ctx* ctx, se3tn_mesh* mesh, const double ob_in_cam[16], const double K[9], int W, int H,
+                       uint8_t* rgb, uint16_t* depth, void* stream);
+
 /* ---- live-camera front end: depth hole filling ---------------------------------------------------- */
 /* Utils.py:455-514 `fill_depth` as predict_ros.py:38-41 applies it to every depth frame before on_track:
  *     depth = fill_depth(depth_mm / 1e3, max_depth, extrapolate, blur_type);  out_mm = (depth * 1000).astype(uint16)

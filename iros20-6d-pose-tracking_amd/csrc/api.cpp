@@ -76,7 +76,8 @@ struct se3tn_ctx {
   int in_split[2] = {0, 0};                     // pixel format currently held by inA / inB
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
   int* overflow = nullptr;                      // device flag: a split-row store left the f16 range
-  unsigned long long* zbuf = nullptr;           // rasteriser z-buffer keys [176*176]
+  unsigned long long* zbuf = nullptr;           // rasteriser z-buffer keys [zbuf_px] (176*176, grown by se3tn_render_frame)
+  size_t zbuf_px = 0;
   float* fd_buf = nullptr;                      // se3tn_fill_depth scratch: 3 images + minmax[2] + lut[4098]
   size_t fd_pixels = 0;
   bool use_graphs = false;                      // se3tn_enable_graphs
@@ -101,6 +102,12 @@ struct se3tn_mesh {
   int* faces = nullptr;
   float4* vwin = nullptr;
   int V = 0, F = 0;
+  // pyrender-style material (se3tn_mesh_set_texture): uv per vertex, RGB mip pyramid, Kd
+  float* uv = nullptr;
+  uint8_t* tex = nullptr;
+  int tw = 0, th = 0, tlevels = 0;
+  unsigned tex_off[16] = {};
+  float kd[3] = {1.f, 1.f, 1.f};
 };
 
 // ---- Winograd workspaces ----------------------------------------------------------------------------
@@ -187,6 +194,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(split-K workspace)"); }
     e = hipMalloc((void**)&c->zbuf, sizeof(unsigned long long) * RES * RES);
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(zbuf)"); }
+    c->zbuf_px = (size_t)RES * RES;
     e = hipMalloc((void**)&c->overflow, sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->overflow, 0, sizeof(int));
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(overflow flag)"); }
@@ -611,9 +619,47 @@ int se3tn_mesh_create(se3tn_ctx* c, const float* verts, const float* normals, co
   return SE3TN_OK;
 }
 
+int se3tn_mesh_set_texture(se3tn_mesh* m, const float* uv, const uint8_t* rgb, int tw, int th, const float kd[3]) {
+  if (!m || (rgb && (!uv || tw < 1 || th < 1))) return fail(SE3TN_E_ARG, "se3tn_mesh_set_texture: bad argument");
+  if (kd) { m->kd[0] = kd[0]; m->kd[1] = kd[1]; m->kd[2] = kd[2]; }
+  if (m->uv) { (void)hipFree(m->uv); m->uv = nullptr; }
+  if (m->tex) { (void)hipFree(m->tex); m->tex = nullptr; }
+  m->tlevels = 0;
+  if (!rgb) return SE3TN_OK;
+  // mip pyramid: 2x2 box filter per level (what glGenerateMipmap implementations do), levels back to back
+  std::vector<uint8_t> pyr(rgb, rgb + (size_t)tw * th * 3);
+  int w = tw, h = th, levels = 1;
+  size_t off = 0;
+  m->tex_off[0] = 0;
+  while ((w > 1 || h > 1) && levels < 16) {
+    const int nw = w > 1 ? w / 2 : 1, nh = h > 1 ? h / 2 : 1;
+    const size_t noff = off + (size_t)w * h * 3;
+    pyr.resize(noff + (size_t)nw * nh * 3);
+    const uint8_t* src = pyr.data() + off;
+    uint8_t* dst = pyr.data() + noff;
+    for (int y = 0; y < nh; ++y)
+      for (int x = 0; x < nw; ++x)
+        for (int ch = 0; ch < 3; ++ch) {
+          const int x0 = 2 * x < w ? 2 * x : w - 1, x1 = 2 * x + 1 < w ? 2 * x + 1 : w - 1;
+          const int y0 = 2 * y < h ? 2 * y : h - 1, y1 = 2 * y + 1 < h ? 2 * y + 1 : h - 1;
+          const int sum = src[((size_t)y0 * w + x0) * 3 + ch] + src[((size_t)y0 * w + x1) * 3 + ch] +
+                          src[((size_t)y1 * w + x0) * 3 + ch] + src[((size_t)y1 * w + x1) * 3 + ch];
+          dst[((size_t)y * nw + x) * 3 + ch] = (uint8_t)((sum + 2) >> 2);
+        }
+    m->tex_off[levels] = (unsigned)noff;
+    off = noff; w = nw; h = nh; ++levels;
+  }
+  HIPCHK(hipMalloc((void**)&m->tex, pyr.size()));
+  HIPCHK(hipMemcpy(m->tex, pyr.data(), pyr.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&m->uv, sizeof(float) * 2 * m->V));
+  HIPCHK(hipMemcpy(m->uv, uv, sizeof(float) * 2 * m->V, hipMemcpyHostToDevice));
+  m->tw = tw; m->th = th; m->tlevels = levels;
+  return SE3TN_OK;
+}
+
 void se3tn_mesh_destroy(se3tn_mesh* m) {
   if (!m) return;
-  void* bufs[] = {m->verts, m->normals, m->colors, m->faces, m->vwin};
+  void* bufs[] = {m->verts, m->normals, m->colors, m->faces, m->vwin, m->uv, m->tex};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete m;
@@ -627,6 +673,7 @@ int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const 
   RasterArgs a{};
   a.verts = m->verts; a.normals = m->normals; a.colors = m->colors; a.faces = m->faces; a.vwin = m->vwin;
   a.zbuf = c->zbuf; a.rgb = rgb; a.depth = depth; a.V = m->V; a.F = m->F;
+  a.rw = RES; a.rh = RES; a.mode = 0;
   for (int i = 0; i < 12; ++i) a.M[i] = (float)ob_in_cam[i];
   a.fx = (float)K[0]; a.fy = (float)K[4]; a.cx = (float)K[2]; a.cy = (float)K[5];
   a.left = (float)window[0]; a.top = (float)window[1]; a.right = (float)window[2]; a.bottom = (float)window[3];
@@ -661,6 +708,34 @@ int se3tn_fill_depth(se3tn_ctx* c, const uint16_t* depth_mm, int H, int W, doubl
   a.lut = c->fd_buf + 3 * px + 2;
   a.out_mm = out_mm; a.out_m = out_m;
   HIPCHK(launch_fill_depth(a, (hipStream_t)stream));
+  return SE3TN_OK;
+}
+
+int se3tn_render_frame(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const double K[9], int W, int H, uint8_t* rgb,
+                       uint16_t* depth, void* stream) {
+  if (!c || c->device < 0 || !m || !ob_in_cam || !K || !rgb || !depth || W < 1 || H < 1)
+    return fail(SE3TN_E_ARG, "se3tn_render_frame: bad argument");
+  const size_t px = (size_t)W * H;
+  if (px > c->zbuf_px) {   // first full-frame render (start-up): a z-buffer of the camera's size
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    (void)hipFree(c->zbuf);
+    c->zbuf = nullptr; c->zbuf_px = 0;
+    HIPCHK(hipMalloc((void**)&c->zbuf, sizeof(unsigned long long) * px));
+    c->zbuf_px = px;
+  }
+  RasterArgs a{};
+  a.verts = m->verts; a.normals = m->normals; a.colors = m->colors; a.faces = m->faces; a.vwin = m->vwin;
+  a.zbuf = c->zbuf; a.rgb = rgb; a.depth = depth; a.V = m->V; a.F = m->F;
+  a.rw = W; a.rh = H; a.mode = 1;
+  a.uv = m->uv; a.tex = m->tex; a.tw = m->tw; a.th = m->th; a.tlevels = m->tlevels;
+  for (int i = 0; i < 16; ++i) a.tex_off[i] = m->tex_off[i];
+  a.kd[0] = m->kd[0]; a.kd[1] = m->kd[1]; a.kd[2] = m->kd[2];
+  for (int i = 0; i < 12; ++i) a.M[i] = (float)ob_in_cam[i];
+  a.fx = (float)K[0]; a.fy = (float)K[4]; a.cx = (float)K[2]; a.cy = (float)K[5];
+  // IntrinsicsCamera at W x H: window x = u, row r = v  <=>  the Vispy-style window (left, top, right, bottom) =
+  // (0, 2 cy - H, W, 2 cy) in (u, cy - fy y / z) coordinates (raster.hip)
+  a.left = 0.f; a.right = (float)W; a.top = 2.f * a.cy - (float)H; a.bottom = 2.f * a.cy;
+  HIPCHK(launch_raster(a, (hipStream_t)stream));
   return SE3TN_OK;
 }
 

@@ -20,6 +20,13 @@
 //   * read-back (:160-169): rows bottom-up (=> top-down in the OpenCV image), distance recovered from
 //     the depth buffer = camera z, background 0, depth_mm = uint16(z * 1000).
 //
+// Second mode (a.mode == 1): the reference's OTHER renderer, offscreen_renderer.py:48-83 (pyrender), selected by
+// dataset_info['renderer'] == 'pyrenderer' (predict.py:161-164) for textured .obj models: a FULL camera frame
+// (IntrinsicsCamera(fx,fy,cx,cy, znear 0.1, zfar 2.0): pixel (i, r) covers u in [i,i+1), v in [r,r+1)), the scene lit
+// by ambient light [1,1,1] only -> fragment colour = base colour (Kd x texture, trilinear with box-filtered mip levels,
+// REPEAT wrap; or the vertex colour), depth returned as linear camera z; Tracker.render_window then crops it with
+// crop_bbox (predict.py:209-213).  Parity with pyrender's shader / a GL driver's texture filtering is unpinned.
+//
 // Three kernels: vertices -> window space; one thread per triangle scatters (depth | triangle id) keys
 // with 64-bit atomicMin (deterministic z-buffer, ties broken by triangle index); one thread per pixel
 // re-derives the barycentrics of the winning triangle, interpolates and shades.
@@ -43,7 +50,7 @@ __global__ __launch_bounds__(256) void raster_vertex_kernel(const RasterArgs a) 
   // z_ndc = -A + B / z with A = -(n+f)/(f-n), B = -2nf/(f-n)
   const float A = -(R_NEAR + R_FAR) / (R_FAR - R_NEAR), B = -2.f * R_NEAR * R_FAR / (R_FAR - R_NEAR);
   const float zn = -A + B * iw;
-  a.vwin[i] = make_float4((xn + 1.f) * (RES * 0.5f), (yn + 1.f) * (RES * 0.5f), (zn + 1.f) * 0.5f, z > 0.f ? iw : -1.f);
+  a.vwin[i] = make_float4((xn + 1.f) * (a.rw * 0.5f), (yn + 1.f) * (a.rh * 0.5f), (zn + 1.f) * 0.5f, z > 0.f ? iw : -1.f);
 }
 
 __device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by, float px, float py) {
@@ -80,8 +87,8 @@ __global__ __launch_bounds__(256) void raster_triangle_kernel(const RasterArgs a
   if (area < 0.f) { const float4 tmp = v1; v1 = v2; v2 = tmp; area = -area; }  // orient counter-clockwise
   const float xmin = fminf(v0.x, fminf(v1.x, v2.x)), xmax = fmaxf(v0.x, fmaxf(v1.x, v2.x));
   const float ymin = fminf(v0.y, fminf(v1.y, v2.y)), ymax = fmaxf(v0.y, fmaxf(v1.y, v2.y));
-  const int i0 = max(0, (int)floorf(xmin - 0.5f)), i1 = min(RES - 1, (int)ceilf(xmax - 0.5f));
-  const int j0 = max(0, (int)floorf(ymin - 0.5f)), j1 = min(RES - 1, (int)ceilf(ymax - 0.5f));
+  const int i0 = max(0, (int)floorf(xmin - 0.5f)), i1 = min(a.rw - 1, (int)ceilf(xmax - 0.5f));
+  const int j0 = max(0, (int)floorf(ymin - 0.5f)), j1 = min(a.rh - 1, (int)ceilf(ymax - 0.5f));
   for (int j = j0; j <= j1; ++j)
     for (int i = i0; i <= i1; ++i) {
       float l0, l1, l2;
@@ -89,17 +96,37 @@ __global__ __launch_bounds__(256) void raster_triangle_kernel(const RasterArgs a
       const float zw = l0 * v0.z + l1 * v1.z + l2 * v2.z;
       if (!(zw >= 0.f && zw < 1.f)) continue;  // near / far planes; LESS against the cleared 1.0
       const unsigned long long key = ((unsigned long long)__float_as_uint(zw) << 32) | (unsigned)t;
-      atomicMin(a.zbuf + j * RES + i, key);
+      atomicMin(a.zbuf + j * a.rw + i, key);
     }
+}
+
+// texel (x, y) of mip level l (RGB uint8, levels stored back to back, level l is max(tw >> l, 1) x max(th >> l, 1)); REPEAT wrap
+__device__ __forceinline__ void sample_bilinear(const RasterArgs& a, int level, float u, float v, float* out) {
+  const int w = max(a.tw >> level, 1), h = max(a.th >> level, 1);
+  const uint8_t* base = a.tex + a.tex_off[level];
+  // image row 0 is the TOP of the picture, v = 0 its bottom (OBJ / GL convention)
+  const float x = u * w - 0.5f, y = (1.0f - v) * h - 0.5f;
+  const float xf = floorf(x), yf = floorf(y);
+  const float ax = x - xf, ay = y - yf;
+  int x0 = (int)xf % w, y0 = (int)yf % h;
+  if (x0 < 0) x0 += w;
+  if (y0 < 0) y0 += h;
+  const int x1 = (x0 + 1) % w, y1 = (y0 + 1) % h;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float t00 = base[((size_t)y0 * w + x0) * 3 + c], t10 = base[((size_t)y0 * w + x1) * 3 + c];
+    const float t01 = base[((size_t)y1 * w + x0) * 3 + c], t11 = base[((size_t)y1 * w + x1) * 3 + c];
+    out[c] = (t00 * (1.f - ax) + t10 * ax) * (1.f - ay) + (t01 * (1.f - ax) + t11 * ax) * ay;
+  }
 }
 
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const RasterArgs a) {
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= RES * RES) return;
+  if (p >= a.rw * a.rh) return;
   // GL window row j counts bottom-up, and glReadPixels returns rows in that order; the reference
   // reshapes the buffer as-is.  `bottom` is the LARGER Y = cy - fy y/z, i.e. the smaller OpenCV v, so
   // array row j is already top-down in the OpenCV image: output index = window index.
-  const int j = p / RES, i = p - j * RES;
+  const int j = p / a.rw, i = p - j * a.rw;
   const unsigned long long key = a.zbuf[p];
   uint8_t* rgb = a.rgb + (size_t)p * 3;
   if (key == ~0ull) {
@@ -124,6 +151,44 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const RasterArgs a)
   const float q0 = l0 * v0.w, q1 = l1 * v1.w, q2 = l2 * v2.w;
   const float iq = 1.0f / (q0 + q1 + q2);
   const float b0 = q0 * iq, b1 = q1 * iq, b2 = q2 * iq;
+  const float zw = __uint_as_float((unsigned)(key >> 32));
+  const float A = -(R_NEAR + R_FAR) / (R_FAR - R_NEAR), B = -2.f * R_NEAR * R_FAR / (R_FAR - R_NEAR);
+  const float dist = B / (zw * -2.0f + 1.0f - A) * -1.0f;   // linear depth recovered from the depth buffer == camera z
+  if (a.mode == 1) {
+    // pyrender, ambient light only: colour = Kd * (texture | vertex colour); no lighting term
+    float col[3];
+    if (a.tex) {
+      // perspective-correct uv at this pixel and at its right / upper neighbours -> level of detail
+      float uv[3][2];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        float m0, m1, m2;
+        covers(v0, v1, v2, area, i + 0.5f + (s == 1 ? 1.f : 0.f), j + 0.5f + (s == 2 ? 1.f : 0.f), m0, m1, m2);
+        const float r0 = m0 * v0.w, r1 = m1 * v1.w, r2 = m2 * v2.w, ir = 1.0f / (r0 + r1 + r2);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          uv[s][c] = (r0 * a.uv[2 * f0 + c] + r1 * a.uv[2 * f1 + c] + r2 * a.uv[2 * f2 + c]) * ir;
+      }
+      const float dudx = (uv[1][0] - uv[0][0]) * a.tw, dvdx = (uv[1][1] - uv[0][1]) * a.th;
+      const float dudy = (uv[2][0] - uv[0][0]) * a.tw, dvdy = (uv[2][1] - uv[0][1]) * a.th;
+      const float rho = fmaxf(sqrtf(dudx * dudx + dvdx * dvdx), sqrtf(dudy * dudy + dvdy * dvdy));
+      const float lod = fminf(fmaxf(log2f(fmaxf(rho, 1e-8f)), 0.f), (float)(a.tlevels - 1));
+      const int l0i = (int)floorf(lod), l1i = min(l0i + 1, a.tlevels - 1);
+      const float fl = lod - (float)l0i;
+      float c0[3], c1[3];
+      sample_bilinear(a, l0i, uv[0][0], uv[0][1], c0);
+      sample_bilinear(a, l1i, uv[0][0], uv[0][1], c1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[c] = (c0[c] + fl * (c1[c] - c0[c])) * (1.0f / 255.0f);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[c] = b0 * a.colors[3 * f0 + c] + b1 * a.colors[3 * f1 + c] + b2 * a.colors[3 * f2 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] = (uint8_t)(int)rintf(fminf(fmaxf(col[c] * a.kd[c], 0.f), 1.f) * 255.f);
+    a.depth[p] = (uint16_t)(dist * 1000.f);      // (depth * 1000).astype(np.uint16), predict.py:211
+    return;
+  }
   float pos[3], nrm[3], col[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -141,18 +206,15 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const RasterArgs a)
     rgb[c] = (uint8_t)(int)rintf(v * 255.f);
   }
   // distance = B / (zw * -2 + 1 - A) * -1  (vispy_renderer.py:164-169) == camera z
-  const float zw = __uint_as_float((unsigned)(key >> 32));
-  const float A = -(R_NEAR + R_FAR) / (R_FAR - R_NEAR), B = -2.f * R_NEAR * R_FAR / (R_FAR - R_NEAR);
-  const float dist = B / (zw * -2.0f + 1.0f - A) * -1.0f;
   a.depth[p] = (dist >= B / (A + 1.f)) ? (uint16_t)0 : (uint16_t)(dist * 1000.f);
 }
 
 hipError_t launch_raster(const RasterArgs& a, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(a.zbuf, 0xff, sizeof(unsigned long long) * RES * RES, st);
+  hipError_t e = hipMemsetAsync(a.zbuf, 0xff, sizeof(unsigned long long) * a.rw * a.rh, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(raster_vertex_kernel, dim3((a.V + 255) / 256), dim3(256), 0, st, a);
   hipLaunchKernelGGL(raster_triangle_kernel, dim3((a.F + 255) / 256), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(raster_resolve_kernel, dim3((RES * RES + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(raster_resolve_kernel, dim3((a.rw * a.rh + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -221,14 +221,21 @@ struct RasterArgs {
   const float* colors;   // [V,3] in [0,1]
   const int* faces;      // [F,3]
   float4* vwin;          // [V] scratch: window-space x, y, depth in [0,1], 1/w
-  unsigned long long* zbuf;  // [176*176] scratch
-  uint8_t* rgb;          // out [176,176,3]
-  uint16_t* depth;       // out [176,176] millimetres
+  unsigned long long* zbuf;  // [rw*rh] scratch
+  uint8_t* rgb;          // out [rh,rw,3]
+  uint16_t* depth;       // out [rh,rw] millimetres
   float M[12];           // ob_in_cv_cam rows 0..2 (R | t)
   float fx, fy, cx, cy;
   float left, right, top, bottom;  // window in (X, Y) coordinates, Y = cy - fy y / z
   float light[3];        // light_direction in object space
   int V, F;
+  int rw, rh;            // output resolution (176 x 176 for the Vispy-style window, the camera frame in pyrender mode)
+  int mode;              // 0: VispyRenderer (Lambert shader, window crop)   1: pyrender (ambient only, full frame)
+  const float* uv;       // mode 1: [V,2] texture coordinates or nullptr
+  const uint8_t* tex;    // mode 1: RGB uint8 mip pyramid or nullptr (then the vertex colours are the base colour)
+  int tw, th, tlevels;
+  unsigned tex_off[16];  // byte offset of every mip level
+  float kd[3];           // base colour factor (mtl Kd)
 };
 hipError_t launch_raster(const RasterArgs& a, hipStream_t st);
 

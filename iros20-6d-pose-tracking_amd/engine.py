@@ -168,8 +168,9 @@ class Engine:
         """crop_bbox (Utils.py:320-359) alone: numpy rgb u8 [H,W,3] + depth u16 [H,W], window (left, top, right,
         bottom) -> numpy (rgb u8 [176,176,3], depth u16 [176,176])."""
         dev = "cuda:%d" % self.device
-        rgb_d = torch.from_numpy(np.ascontiguousarray(rgb, dtype=np.uint8)).to(dev)
-        dep_d = torch.from_numpy(np.ascontiguousarray(depth, dtype=np.uint16).view(np.int16)).to(dev)
+        rgb_d = rgb if torch.is_tensor(rgb) else torch.from_numpy(np.ascontiguousarray(rgb, dtype=np.uint8)).to(dev)
+        dep_d = depth if torch.is_tensor(depth) else torch.from_numpy(np.ascontiguousarray(depth, dtype=np.uint16).view(np.int16)).to(dev)
+        assert rgb_d.is_cuda and dep_d.is_cuda and rgb_d.dtype == torch.uint8 and dep_d.element_size() == 2
         assert rgb_d.dim() == 3 and rgb_d.shape[2] == 3 and tuple(dep_d.shape) == tuple(rgb_d.shape[:2])
         c = Crop()
         c.rgb = rgb_d.data_ptr(); c.depth = dep_d.data_ptr()

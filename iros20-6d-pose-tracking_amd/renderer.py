@@ -12,12 +12,21 @@ from .engine import _stream_ptr
 
 
 class HipRenderer:
-    def __init__(self, engine, model, resolution=176):
-        """model: path to a .ply with faces / vertex colours / normals, or a dict with
-        vertices [V,3], faces [F,3], colors [V,3] (0..255), normals [V,3] (optional)."""
-        assert resolution == 176
+    def __init__(self, engine, model, resolution=176, mode="vispy", frame_size=None):
+        """model: path to a .ply with faces / vertex colours / normals (or a textured .obj), or a dict with
+        vertices [V,3], faces [F,3], colors [V,3] (0..255), normals [V,3] (optional), and for mode 'pyrender'
+        optionally uv [V,2], texture uint8 [h,w,3], kd [3].
+        mode 'vispy': the reference's VispyRenderer (176 x 176 window, Lambert shader); mode 'pyrender': its
+        offscreen_renderer.Renderer (full camera frame of frame_size = (H, W), ambient light only), selected by
+        dataset_info['renderer'] == 'pyrenderer' (predict.py:161-164)."""
+        assert resolution == 176 and mode in ("vispy", "pyrender")
         self.engine = engine
-        mesh = U.load_ply_mesh(model) if isinstance(model, str) else model
+        self.mode = mode
+        self.full_frame = mode == "pyrender"
+        if isinstance(model, str):
+            mesh = U.load_obj_mesh(model) if model.endswith(".obj") else U.load_ply_mesh(model)
+        else:
+            mesh = model
         v = np.ascontiguousarray(mesh["vertices"], np.float32)
         f = np.ascontiguousarray(mesh["faces"], np.int32)
         col = np.ascontiguousarray(np.asarray(mesh["colors"], np.float64) / 255.0, np.float32)
@@ -32,6 +41,21 @@ class HipRenderer:
                                            f.ctypes.data, len(f), C.byref(h)), "se3tn_mesh_create")
         self._m = h
         dev = "cuda:%d" % engine.device
+        if self.full_frame:
+            assert frame_size is not None, "mode 'pyrender' renders the whole camera frame: pass frame_size=(H, W)"
+            uv, texture = mesh.get("uv"), mesh.get("texture")
+            kd = (C.c_float * 3)(*[float(x) for x in mesh.get("kd", (1.0, 1.0, 1.0))])
+            if texture is not None and uv is not None:
+                uv32 = np.ascontiguousarray(uv, np.float32)
+                tex = np.ascontiguousarray(texture, np.uint8)
+                check(engine.lib.se3tn_mesh_set_texture(self._m, uv32.ctypes.data, tex.ctypes.data, tex.shape[1], tex.shape[0], kd),
+                      "se3tn_mesh_set_texture")
+            else:
+                check(engine.lib.se3tn_mesh_set_texture(self._m, None, None, 0, 0, kd), "se3tn_mesh_set_texture")
+            self.H, self.W = int(frame_size[0]), int(frame_size[1])
+            self.rgb = torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=dev)
+            self.depth = torch.empty((self.H, self.W), dtype=torch.int16, device=dev)
+            return
         self.rgb = torch.empty((176, 176, 3), dtype=torch.uint8, device=dev)
         self.depth = torch.empty((176, 176), dtype=torch.int16, device=dev)  # uint16 bits
 
@@ -60,6 +84,21 @@ class HipRenderer:
         check(self.engine.lib.se3tn_render(self.engine._h, self._m, p, k, w, C.c_void_p(rgb.data_ptr()),
                                            C.c_void_p(depth.data_ptr()), _stream_ptr()), "se3tn_render")
         return rgb, depth
+
+    def render_frame_device(self, ob2cam, K):
+        """mode 'pyrender': the full camera frame, on the device (uint8 [H,W,3], uint16-as-int16 [H,W] mm); asynchronous."""
+        assert self.full_frame
+        p = (C.c_double * 16)(*np.asarray(ob2cam, np.float64).reshape(16))
+        k = (C.c_double * 9)(*np.asarray(K, np.float64).reshape(9))
+        check(self.engine.lib.se3tn_render_frame(self.engine._h, self._m, p, k, self.W, self.H, C.c_void_p(self.rgb.data_ptr()),
+                                                 C.c_void_p(self.depth.data_ptr()), _stream_ptr()), "se3tn_render_frame")
+        return self.rgb, self.depth
+
+    def render_frame(self, ob2cam, K):
+        """numpy (rgb uint8 [H,W,3], depth uint16 [H,W] mm) == (color, (depth * 1000).astype(uint16)) of
+        offscreen_renderer.Renderer.render([ob2cam]) (predict.py:210-211)."""
+        rgb, depth = self.render_frame_device(ob2cam, K)
+        return rgb.cpu().numpy(), depth.cpu().numpy().view(np.uint16)
 
     def render(self, ob2cam, K, gl_window):
         """numpy (rgb uint8 [176,176,3], depth uint16 [176,176] mm), like VispyRenderer.render_image."""

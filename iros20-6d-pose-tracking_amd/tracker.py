@@ -59,7 +59,12 @@ class Tracker:
         self.dataset = TrackDataset(self.engine, self.mean, self.std, dataset_info, self.trans_normalizer,
                                     self.rot_normalizer)
         self.renderer = renderer
-        if renderer is None and model_path is not None and model_path.endswith(".ply"):
+        if renderer is None and model_path is not None and dataset_info.get('renderer') == 'pyrenderer':
+            # predict.py:161-164: textured .obj through the pyrender-style full-frame renderer
+            assert '.obj' in model_path
+            from .renderer import HipRenderer
+            self.renderer = HipRenderer(self.engine, model_path, mode="pyrender", frame_size=(cam['height'], cam['width']))
+        elif renderer is None and model_path is not None and model_path.endswith(".ply"):
             # the reference builds a VispyRenderer from the .ply here (predict.py:180-182); ours is the
             # HIP rasteriser -- only if the file has faces (the repo's bunny fixture has none)
             from .renderer import HipRenderer
@@ -98,6 +103,10 @@ class Tracker:
             raise RuntimeError("Tracker.render_window: no renderer injected (rendering is outside the HIP hot path)")
         from .renderer import HipRenderer
         ob2cam = np.asarray(ob2cam, np.float64)
+        if isinstance(self.renderer, HipRenderer) and self.renderer.full_frame:     # predict.py:209-213
+            rgb_d, dep_d = self.renderer.render_frame_device(ob2cam, self.K)
+            bbox = U.compute_bbox(ob2cam, self.K, self.object_width, scale=(1000, 1000, 1000))
+            return self.engine.crop_raw(rgb_d, dep_d, U.crop_window(bbox))
         win = HipRenderer.gl_window(ob2cam, self.K, self.object_width)      # left, top, right, bottom (GL image)
         if hasattr(self.renderer, "update_cam_mat") and hasattr(self.renderer, "render_image"):
             glcam_in_cvcam = np.diag([1.0, -1.0, -1.0, 1.0])
@@ -121,7 +130,13 @@ class Tracker:
         bb = U.compute_bbox(prev_pose, self.K, self.object_width, scale=(1000, 1000, 1000))
         dev = self._dev
         from .renderer import HipRenderer
-        if isinstance(self.renderer, HipRenderer):   # rendered A never leaves the device
+        winA = (0, 0, self.image_size[0], self.image_size[0])
+        if isinstance(self.renderer, HipRenderer) and self.renderer.full_frame:
+            # pyrender route: the full rendered frame stays on the device and is cropped by the same kernel (and the
+            # same bbox) as the camera frame -- predict.py:209-213 without the host round trip
+            rgbA_d, depA_d = self.renderer.render_frame_device(prev_pose, self.K)
+            winA = U.crop_window(bb)
+        elif isinstance(self.renderer, HipRenderer):   # rendered A never leaves the device
             rgbA_d, depA_d = self.renderer.render_device(
                 prev_pose, self.K, HipRenderer.gl_window(prev_pose, self.K, self.object_width))
         else:
@@ -135,7 +150,7 @@ class Tracker:
         # the reference evaluates `samples` IDENTICAL hypotheses (only i == 0 sets sample_pose, predict.py:229-231)
         # and returns the first: any count beyond the engine's batch capacity adds nothing -- clamp, never overrun
         n = max(1, min(int(samples), self.engine.max_batch))
-        cropA = dict(rgb=rgbA_d, depth=depA_d, window=(0, 0, res, res), z_offset_mm=z_mm, stats=0)
+        cropA = dict(rgb=rgbA_d, depth=depA_d, window=winA, z_offset_mm=z_mm, stats=0)
         cropB = dict(rgb=rgb_d, depth=dep_d, window=U.crop_window(bb), z_offset_mm=z_mm, stats=1)
         self.engine.preprocess([cropA] * n, self.engine.input_buffer_ptr(0))
         self.engine.preprocess([cropB] * n, self.engine.input_buffer_ptr(1))
@@ -162,7 +177,7 @@ class Tracker:
         poses = np.stack([np.asarray(p, np.float64) for p in prev_poses])
         for i in range(n):
             bb = U.compute_bbox(poses[i], self.K, self.object_width, scale=(1000, 1000, 1000))
-            if isinstance(self.renderer, HipRenderer):
+            if isinstance(self.renderer, HipRenderer) and not self.renderer.full_frame:
                 rgbA_d = torch.empty((176, 176, 3), dtype=torch.uint8, device=dev)
                 depA_d = torch.empty((176, 176), dtype=torch.int16, device=dev)
                 self.renderer.render_device(poses[i], self.K, HipRenderer.gl_window(poses[i], self.K, self.object_width),

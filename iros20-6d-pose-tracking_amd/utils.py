@@ -131,6 +131,68 @@ def load_ply_mesh(path):
     return out
 
 
+def load_obj_mesh(path):
+    """Wavefront .obj as the reference's pyrender route reads it through trimesh (offscreen_renderer.py:60-63):
+    vertices, triangles (polygons fan-triangulated), texture coordinates, the material's diffuse texture (map_Kd)
+    and Kd.  Vertices are split per distinct (position, texcoord) pair so that every vertex carries one uv.
+    Returns dict(vertices [V,3], faces [F,3] int32, uv [V,2] | None, colors [V,3] 0..255, texture uint8 [h,w,3] | None,
+    kd [3], normals None)."""
+    import os
+    pos, tex, col, corners, faces = [], [], [], {}, []
+    mtllib = None
+    out_v, out_uv, out_c = [], [], []
+
+    def corner(tok):
+        parts = tok.split("/")
+        vi = int(parts[0]); vi = vi - 1 if vi > 0 else len(pos) + vi
+        ti = -1
+        if len(parts) > 1 and parts[1]:
+            ti = int(parts[1]); ti = ti - 1 if ti > 0 else len(tex) + ti
+        key = (vi, ti)
+        if key not in corners:
+            corners[key] = len(out_v)
+            out_v.append(pos[vi]); out_c.append(col[vi])
+            out_uv.append(tex[ti] if ti >= 0 else (0.0, 0.0))
+        return corners[key]
+
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                pos.append(tuple(float(x) for x in t[1:4]))
+                col.append(tuple(float(x) * 255.0 for x in t[4:7]) if len(t) >= 7 else (255.0, 255.0, 255.0))
+            elif t[0] == "vt":
+                tex.append((float(t[1]), float(t[2]) if len(t) > 2 else 0.0))
+            elif t[0] == "f":
+                idx = [corner(tok) for tok in t[1:]]
+                for k in range(1, len(idx) - 1):
+                    faces.append((idx[0], idx[k], idx[k + 1]))
+            elif t[0] == "mtllib":
+                mtllib = line.split(None, 1)[1].strip()
+    out = dict(vertices=np.asarray(out_v, np.float64).reshape(-1, 3), faces=np.asarray(faces, np.int32).reshape(-1, 3),
+               uv=np.asarray(out_uv, np.float64).reshape(-1, 2) if tex else None,
+               colors=np.asarray(out_c, np.float64).reshape(-1, 3), texture=None, kd=np.ones(3), normals=None)
+    if mtllib:
+        mpath = os.path.join(os.path.dirname(path), mtllib)
+        if os.path.isfile(mpath):
+            for line in open(mpath):
+                t = line.split()
+                if not t:
+                    continue
+                if t[0] == "Kd" and len(t) >= 4:
+                    out["kd"] = np.array([float(x) for x in t[1:4]])
+                elif t[0] == "map_Kd":
+                    tpath = os.path.join(os.path.dirname(mpath), line.split(None, 1)[1].strip())
+                    if os.path.isfile(tpath):
+                        from PIL import Image
+                        out["texture"] = np.ascontiguousarray(np.array(Image.open(tpath).convert("RGB")), dtype=np.uint8)
+    if out["texture"] is not None and np.all(out["kd"] == 0):
+        out["kd"] = np.ones(3)   # exporters write Kd 0 0 0 next to a map_Kd; trimesh then takes the texture as the colour
+    return out
+
+
 def vertex_normals(vertices, faces):
     """Area-weighted vertex normals for meshes that store none."""
     v = np.asarray(vertices, np.float64)

@@ -114,3 +114,123 @@ def icosphere(subdiv=2, radius=0.05, seed=0):
     rng = np.random.default_rng(seed)
     return dict(vertices=(v * radius).astype(np.float32), faces=np.array(f, np.int32),
                 colors=rng.integers(40, 256, (len(v), 3)).astype(np.float64), normals=v.copy())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's second renderer: offscreen_renderer.py:48-83 (pyrender), used for textured .obj models
+# (predict.py:161-164, :209-213).  Restated as the GL pipeline pyrender sets up: IntrinsicsCamera projection at the
+# camera's W x H, object pose = cvcam_in_glcam . ob_in_cvcam, a scene lit by ambient light [1,1,1] only (fragment
+# colour = base colour = Kd x texture | vertex colour), colour rows flipped to top-down on read-back, depth buffer
+# linearised to metres.  PARITY UNPINNED (no GL / pyrender offline; texture filtering is driver-defined).
+# ------------------------------------------------------------------------------------------------------------------
+def mip_pyramid(tex):
+    """RGB uint8 [h,w,3] -> list of levels, each the 2x2 box filter of the previous (rounded to nearest)."""
+    levels = [np.asarray(tex, np.uint8)]
+    while levels[-1].shape[0] > 1 or levels[-1].shape[1] > 1:
+        t = levels[-1].astype(np.int32)
+        h, w = t.shape[:2]
+        nh, nw = max(h // 2, 1), max(w // 2, 1)
+        ys0 = np.minimum(2 * np.arange(nh), h - 1); ys1 = np.minimum(2 * np.arange(nh) + 1, h - 1)
+        xs0 = np.minimum(2 * np.arange(nw), w - 1); xs1 = np.minimum(2 * np.arange(nw) + 1, w - 1)
+        s = t[ys0][:, xs0] + t[ys0][:, xs1] + t[ys1][:, xs0] + t[ys1][:, xs1]
+        levels.append(((s + 2) >> 2).astype(np.uint8))
+        if len(levels) >= 16:
+            break
+    return levels
+
+
+def _bilinear(level, u, v):
+    h, w = level.shape[:2]
+    x = np.float32(u) * w - np.float32(0.5); y = (np.float32(1.0) - np.float32(v)) * h - np.float32(0.5)
+    xf, yf = np.floor(x), np.floor(y)
+    ax, ay = np.float32(x - xf), np.float32(y - yf)
+    x0, y0 = int(xf) % w, int(yf) % h
+    x1, y1 = (x0 + 1) % w, (y0 + 1) % h
+    t = level.astype(np.float32)
+    return (t[y0, x0] * (1 - ax) + t[y0, x1] * ax) * (1 - ay) + (t[y1, x0] * (1 - ax) + t[y1, x1] * ax) * ay
+
+
+def render_frame(vertices, colors01, faces, ob2cam, K, W, H, uv=None, texture=None, kd=(1.0, 1.0, 1.0), near=0.1, far=2.0):
+    """Returns rgb uint8 [H,W,3] and depth uint16 [H,W] = (pyrender depth * 1000).astype(uint16) (predict.py:211)."""
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    P = np.zeros((4, 4))
+    P[0, 0] = 2.0 * fx / W; P[1, 1] = 2.0 * fy / H
+    P[0, 2] = 1.0 - 2.0 * cx / W; P[1, 2] = 2.0 * cy / H - 1.0
+    P[2, 2] = (far + near) / (near - far); P[2, 3] = 2 * far * near / (near - far); P[3, 2] = -1.0
+    V = np.diag([1.0, -1.0, -1.0, 1.0]).dot(ob2cam)         # cvcam_in_glcam . ob_in_cvcam (offscreen_renderer.py:80)
+    PV = (P @ V).astype(np.float32)
+    vh = np.concatenate([vertices.astype(np.float32), np.ones((len(vertices), 1), np.float32)], 1)
+    clip = vh @ PV.T
+    w = clip[:, 3]
+    ndc = clip[:, :3] / w[:, None]
+    win = np.stack([(ndc[:, 0] + 1) * W / 2, (ndc[:, 1] + 1) * H / 2, (ndc[:, 2] + 1) / 2], 1).astype(np.float32)
+    zbuf = np.ones((H, W), np.float32)
+    rgb = np.zeros((H, W, 3), np.uint8)
+    hit = np.zeros((H, W), bool)
+    levels = mip_pyramid(texture) if texture is not None else None
+    kd = np.asarray(kd, np.float32)
+
+    def edge(a, b, px, py):
+        return (b[0] - a[0]) * (py - a[1]) - (b[1] - a[1]) * (px - a[0])
+
+    def top_left(a, b):
+        dx, dy = b[0] - a[0], b[1] - a[1]
+        return dy < 0 or (dy == 0 and dx < 0)
+
+    def bary(v0, v1, v2, area, px, py):
+        e = np.array([edge(v1, v2, px, py), edge(v2, v0, px, py), edge(v0, v1, px, py)], np.float32)
+        return e, e * (np.float32(1.0) / area)
+
+    for t in range(len(faces)):
+        ids = list(faces[t])
+        if (w[ids] <= 0).any():
+            continue
+        v0, v1, v2 = win[ids[0]], win[ids[1]], win[ids[2]]
+        area = np.float32(edge(v0, v1, v2[0], v2[1]))
+        if area == 0 or np.isnan(area):
+            continue
+        if area < 0:
+            ids[1], ids[2] = ids[2], ids[1]
+            v1, v2 = v2, v1
+            area = -area
+        i0 = max(0, int(np.floor(min(v0[0], v1[0], v2[0]) - 0.5))); i1 = min(W - 1, int(np.ceil(max(v0[0], v1[0], v2[0]) - 0.5)))
+        j0 = max(0, int(np.floor(min(v0[1], v1[1], v2[1]) - 0.5))); j1 = min(H - 1, int(np.ceil(max(v0[1], v1[1], v2[1]) - 0.5)))
+        iw = (np.float32(1.0) / w[ids]).astype(np.float32)
+        for j in range(j0, j1 + 1):
+            for i in range(i0, i1 + 1):
+                px, py = np.float32(i + 0.5), np.float32(j + 0.5)
+                e, l = bary(v0, v1, v2, area, px, py)
+                if not ((e[0] > 0 or (e[0] == 0 and top_left(v1, v2))) and (e[1] > 0 or (e[1] == 0 and top_left(v2, v0)))
+                        and (e[2] > 0 or (e[2] == 0 and top_left(v0, v1)))):
+                    continue
+                zw = np.float32(l[0] * v0[2] + l[1] * v1[2] + l[2] * v2[2])
+                if not (0 <= zw < 1) or not (zw < zbuf[j, i]):
+                    continue
+                zbuf[j, i] = zw
+                hit[j, i] = True
+                if levels is not None:
+                    uvs = []
+                    for (ox, oy) in ((0, 0), (1, 0), (0, 1)):
+                        _, m = bary(v0, v1, v2, area, px + np.float32(ox), py + np.float32(oy))
+                        q = m * iw
+                        uvs.append((q / q.sum()).astype(np.float32) @ uv[ids].astype(np.float32))
+                    th, tw = levels[0].shape[:2]
+                    dx = (uvs[1] - uvs[0]) * np.array([tw, th], np.float32)
+                    dy = (uvs[2] - uvs[0]) * np.array([tw, th], np.float32)
+                    rho = max(float(np.sqrt((dx * dx).sum())), float(np.sqrt((dy * dy).sum())))
+                    lod = min(max(np.log2(max(rho, 1e-8)), 0.0), len(levels) - 1)
+                    l0 = int(np.floor(lod)); l1 = min(l0 + 1, len(levels) - 1); fl = np.float32(lod - l0)
+                    c0 = _bilinear(levels[l0], uvs[0][0], uvs[0][1]); c1 = _bilinear(levels[l1], uvs[0][0], uvs[0][1])
+                    col = (c0 + fl * (c1 - c0)) / np.float32(255.0)
+                else:
+                    q = l * iw
+                    col = (q / q.sum()).astype(np.float32) @ colors01[ids].astype(np.float32)
+                rgb[j, i] = np.rint(np.clip(col * kd, 0, 1) * 255).astype(np.uint8)
+    # window rows count bottom-up from Y = H - v: row j of this buffer already is image row j of the mapping used above?
+    # NO: here win y = (y_ndc + 1) H / 2 with y_ndc = 1 - 2 v / H  ->  win y = H - v: bottom-up.  pyrender flips on read-back.
+    rgb = rgb[::-1].copy(); zbuf = zbuf[::-1].copy(); hit = hit[::-1].copy()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z_ndc = zbuf * np.float32(2.0) - np.float32(1.0)
+        depth = (np.float32(2.0 * near * far) / (np.float32(far + near) - z_ndc * np.float32(far - near))).astype(np.float32)
+    depth[~hit] = 0
+    return rgb, (depth * 1000).astype(np.uint16)

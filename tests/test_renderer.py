@@ -91,3 +91,107 @@ def test_tracker_with_builtin_renderer(se3, tmp_path):
     P1 = trk.on_track(P0, rgb, depth)
     want, _ = O.on_track(sd, P0, rgb, depth, rgbA, depthA, Fx.K_YCB, 150.0, mean, std)
     assert np.abs(P1 - want).max() < 1e-5
+
+
+# ---- the reference's second renderer (pyrender, textured .obj): offscreen_renderer.py:48-83, predict.py:161-164,209-213 ----
+def _textured_sphere(tmp_path, subdiv=2, radius=0.05, tex_hw=(64, 128)):
+    """icosphere with spherical texture coordinates, written as .obj + .mtl + .png; returns (paths, mesh dict)."""
+    from PIL import Image
+    m = R.icosphere(subdiv, radius, 3)
+    v = m["vertices"].astype(np.float64)
+    n = v / np.linalg.norm(v, axis=1, keepdims=True)
+    uv = np.stack([0.5 + np.arctan2(n[:, 1], n[:, 0]) / (2 * np.pi), 0.5 + np.arcsin(np.clip(n[:, 2], -1, 1)) / np.pi], 1)
+    rng = np.random.default_rng(9)
+    th, tw = tex_hw
+    yy, xx = np.mgrid[0:th, 0:tw]
+    tex = np.stack([(xx * 255 // (tw - 1)), (yy * 255 // (th - 1)), ((xx // 8 + yy // 8) % 2) * 200 + 30], -1).astype(np.uint8)
+    tex[rng.random((th, tw)) < 0.05] = (255, 255, 255)
+    Image.fromarray(tex).save(tmp_path / "tex.png")
+    (tmp_path / "obj.mtl").write_text("newmtl m0\nKa 0.2 0.2 0.2\nKd 0.9 1.0 0.8\nmap_Kd tex.png\n")
+    with open(tmp_path / "obj.obj", "w") as f:
+        f.write("mtllib obj.mtl\nusemtl m0\n")
+        for p in v:
+            f.write("v %.9f %.9f %.9f\n" % tuple(p))
+        for t in uv:
+            f.write("vt %.9f %.9f\n" % tuple(t))
+        for a, b, c in m["faces"]:
+            f.write("f %d/%d %d/%d %d/%d\n" % (a + 1, a + 1, b + 1, b + 1, c + 1, c + 1))
+    return str(tmp_path / "obj.obj"), dict(vertices=v, faces=m["faces"], uv=uv, texture=tex, kd=np.array([0.9, 1.0, 0.8]))
+
+
+def test_obj_loader_and_mip_pyramid(se3, tmp_path):
+    path, want = _textured_sphere(tmp_path)
+    got = se3.utils.load_obj_mesh(path)
+    # (vertices are numbered in order of first use by a face: compare per face corner)
+    assert got["vertices"].shape == want["vertices"].shape and got["faces"].shape == want["faces"].shape
+    assert np.allclose(got["vertices"][got["faces"]], want["vertices"][want["faces"]], atol=1e-8)
+    assert np.allclose(got["uv"][got["faces"]], want["uv"][want["faces"]], atol=1e-8)
+    assert np.array_equal(got["texture"], want["texture"]) and np.allclose(got["kd"], want["kd"])
+    # quads are fan-triangulated, negative indices are relative, a vertex used with two texcoords is split
+    (tmp_path / "q.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvt 0.5 0.5\n"
+                                    "f 1/1 2/2 3/3 4/4\nf -4/5 -3/2 -2/3\n")
+    q = se3.utils.load_obj_mesh(str(tmp_path / "q.obj"))
+    assert q["faces"].tolist() == [[0, 1, 2], [0, 2, 3], [4, 1, 2]] and len(q["vertices"]) == 5 and q["texture"] is None
+    lv = R.mip_pyramid(want["texture"])
+    assert [l.shape[:2] for l in lv][:4] == [(64, 128), (32, 64), (16, 32), (8, 16)] and lv[-1].shape[:2] == (1, 1)
+    assert abs(int(lv[-1][0, 0, 0]) - int(want["texture"][..., 0].mean())) <= 2
+
+
+@pytest.mark.gpu
+def test_hip_full_frame_renderer_vs_pyrender_oracle(se3, tmp_path):
+    path, mesh = _textured_sphere(tmp_path, subdiv=2)
+    eng = se3.Engine(0, 1)
+    H, W = 120, 160
+    K = np.array([[266.7, 0, 78.2], [0, 266.9, 60.3], [0, 0, 1.0]])
+    for textured in (True, False):
+        model = path if textured else dict(vertices=mesh["vertices"], faces=mesh["faces"],
+                                           colors=R.icosphere(2, 0.05, 3)["colors"], kd=(1.0, 0.9, 0.8))
+        ren = se3.HipRenderer(eng, model, mode="pyrender", frame_size=(H, W))
+        P = Fx.pose(4, (0.01, -0.02, 0.45))
+        rgb, depth = ren.render_frame(P, K)
+        if textured:
+            orgb, odepth = R.render_frame(mesh["vertices"].astype(np.float32), None, mesh["faces"], P, K, W, H,
+                                          uv=mesh["uv"], texture=mesh["texture"], kd=mesh["kd"])
+        else:
+            orgb, odepth = R.render_frame(model["vertices"].astype(np.float32), (model["colors"] / 255.0).astype(np.float32),
+                                          model["faces"], P, K, W, H, kd=model["kd"])
+        assert rgb.shape == (H, W, 3) and depth.dtype == np.uint16 and depth.shape == (H, W)
+        assert ((depth > 0) == (odepth > 0)).mean() > 0.9995
+        both = (depth > 0) & (odepth > 0)
+        assert both.sum() > 1500
+        assert np.abs(depth[both].astype(int) - odepth[both].astype(int)).max() <= 1
+        d = np.abs(rgb[both].astype(int) - orgb[both].astype(int))
+        # texture filtering: the level of detail is taken from finite differences at the pixel; identical algorithm,
+        # float32 rounding can move a texel boundary
+        assert np.median(d) <= 1 and (d > 6).mean() < 0.02, (np.median(d), (d > 6).mean())
+        assert (rgb[~(depth > 0)] == 0).all()
+        # the sphere's centre projects to (fx x/z + cx, fy y/z + cy): pixel i covers u in [i, i+1)
+        ys, xs = np.nonzero(depth)
+        u = K[0, 0] * P[0, 3] / P[2, 3] + K[0, 2]; v = K[1, 1] * P[1, 3] / P[2, 3] + K[1, 2]
+        assert abs(xs.mean() + 0.5 - u) < 1.0 and abs(ys.mean() + 0.5 - v) < 1.0
+        assert 450 - 51 <= depth[depth > 0].min() <= 450 - 45
+
+
+@pytest.mark.gpu
+def test_tracker_pyrenderer_route(se3, tmp_path):
+    """dataset_info['renderer'] == 'pyrenderer' + a textured .obj (predict.py:161-164): render_window = crop_bbox of
+    the full-frame render (predict.py:209-213), and on_track (rendered frame cropped on the device) equals the oracle
+    composition fed that crop."""
+    from oracle import se3_oracle as O
+    path, mesh = _textured_sphere(tmp_path, subdiv=3, radius=0.06)
+    sd = O.make_state_dict(0, head_gain=0.002)
+    mean, std = Fx.mean_std(0)
+    info = dict(Fx.DATASET_INFO); info["object_width"] = 150.0; info["renderer"] = "pyrenderer"
+    trk = se3.Tracker(info, mean, std, {"state_dict": sd}, model_path=path)
+    assert isinstance(trk.renderer, se3.HipRenderer) and trk.renderer.full_frame and trk.object_cloud is not None
+    P0 = Fx.pose(3, (0.03, -0.01, 0.7))
+    full_rgb, full_depth = trk.renderer.render_frame(P0, trk.K)
+    assert full_rgb.shape == (480, 640, 3)
+    rgbA, depthA = trk.render_window(P0)
+    bb = O.compute_bbox(P0, Fx.K_YCB, 150.0, scale=(1000, 1000, 1000))
+    wantA, wantD = O.crop_bbox(full_rgb, full_depth, bb, (176, 176))
+    assert (rgbA == wantA).all() and (depthA == wantD).all() and (depthA > 100).sum() > 3000
+    rgb, depth = Fx.synthetic_frame(12)
+    P1 = trk.on_track(P0, rgb, depth)
+    want, _ = O.on_track(sd, P0, rgb, depth, rgbA, depthA, Fx.K_YCB, 150.0, mean, std)
+    assert np.abs(P1 - want).max() < 1e-5
