@@ -77,6 +77,7 @@ def run(se3, frames=300, check=True, subdiv=5, precision=None, timing=True):
         e_net = e_pose = 0.0
         drift = 0.0
         replay_diff = 0.0
+        reinits_c = 0
         for f in range(frames):
             rgb, depth = seq[f % N_DISTINCT_FRAMES]
             Pn = trk.on_track(P, rgb, depth)
@@ -91,9 +92,13 @@ def run(se3, frames=300, check=True, subdiv=5, precision=None, timing=True):
             if poses_timed is not None:
                 replay_diff = max(replay_diff, float(np.abs(Pn - poses_timed[f]).max()))
             drift = max(drift, float(np.linalg.norm(Pn[:3, 3] - P0[:3, 3])))
-            P = P0.copy() if _lost(Pn) else Pn
+            if _lost(Pn):
+                reinits_c += 1
+                P = P0.copy()
+            else:
+                P = Pn
         out.update(frames_checked=frames, bbox_mismatches=bbox_mismatch, max_abs_trans_rot=e_net, max_abs_pose=e_pose,
-                   tol_trans_rot=1e-4, tol_pose=1e-5, max_drift_m=round(drift, 4),
+                   tol_trans_rot=1e-4, tol_pose=1e-5, max_drift_m=round(drift, 4), reinits_checked_pass=reinits_c,
                    ok=bool(bbox_mismatch == 0 and e_net <= 1e-4 and e_pose <= 1e-5))
         if poses_timed is not None:
             out["timed_vs_checked_pass_max_abs_pose"] = replay_diff   # the two passes are the same deterministic track
