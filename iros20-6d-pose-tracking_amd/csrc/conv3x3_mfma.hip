@@ -278,9 +278,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_slab_kernel(const ConvArgs a) 
 // =================================================================================================
 // stride 2: gather kernel, 4 waves = 2 x 2, wave tile 2 x 2 tiles (128 px x 128 cout), 2 WGs per CU
 // =================================================================================================
-template <int CIN, int EPI, int MM, int OUTF>
-__global__ __launch_bounds__(256, 2) void conv3x3_gather_s2_kernel(const ConvArgs a) {
-  constexpr int BM = 128, BN = 128, PT = 2, CT = 2;
+// NW = 4: 128 px x 128 cout, 2 workgroups per CU (small batches: more, smaller tiles);  NW = 8: 256 px x 128 cout, one
+// workgroup per CU: 48 KB instead of 2 x 32 KB of operands DMA'd per K-step for the same flops (the DMA, not the MFMA
+// stream, is what these kernels lose time to: scripts/probes/mfma_stream.hip)
+template <int CIN, int EPI, int MM, int OUTF, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_gather_s2_kernel(const ConvArgs a) {
+  constexpr int BM = NW * 32, BN = 128, PT = 2, CT = 2;
+  constexpr int RS = NW * 8;          // rows staged per DMA step of the whole workgroup
+  constexpr int PJ = BM / RS, WJ = BN / RS;
   constexpr int NCH = CIN / 32, KT = NCH * 9;
   constexpr int BUF = (BM + BN) * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -304,10 +309,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gather_s2_kernel(const ConvArg
   // (t & 7) ^ ((row >> 1) & 7); in padded coordinates tap (r,s) of output (ho,wo) is input (2ho+r, 2wo+s)
   const int r0 = tid >> 3;
   const int c4 = (tid & 7) ^ ((r0 >> 1) & 7);
-  unsigned pvoff[4];
+  unsigned pvoff[PJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = min(m0 + r0 + 32 * j, mlast);
+  for (int j = 0; j < PJ; ++j) {
+    const int m = min(m0 + r0 + RS * j, mlast);
     const int n = m / HoWo, rem = m - n * HoWo;
     const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
     pvoff[j] = (unsigned)((((n * Hp + 2 * ho) * Wp + 2 * wo) * a.in_ld + c4 * 4) * 4);
@@ -320,15 +325,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gather_s2_kernel(const ConvArg
     const int r_ = (TAP) / 3, s_ = (TAP) - r_ * 3;                                                   \
     const float* pb_ = in + (size_t)(r_ * Wp + s_) * a.in_ld + (CH) * 32;                            \
     const unsigned lb_ = lds0 + (unsigned)(((BUFI) * BUF + wid * 256) * 4);                          \
-    glds16<0>(pb_, pvoff[0], lb_);                                                                   \
-    glds16<0>(pb_, pvoff[1], lb_ + 4096);                                                            \
-    glds16<0>(pb_, pvoff[2], lb_ + 8192);                                                            \
-    glds16<0>(pb_, pvoff[3], lb_ + 12288);                                                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < PJ; ++j_) glds16<0>(pb_, pvoff[j_], lb_ + j_ * RS * 128);  \
     const float* tb_ = wgt + (size_t)((CH) * 9 + (TAP)) * (a.tiles_n * BN) * 32;                     \
-    glds16<0>(tb_, wvoff, lb_ + BM * 128);                                                           \
-    glds16<0>(tb_ + 1024, wvoff, lb_ + BM * 128 + 4096);                                             \
-    glds16<0>(tb_ + 2048, wvoff, lb_ + BM * 128 + 8192);                                             \
-    glds16<0>(tb_ + 3072, wvoff, lb_ + BM * 128 + 12288);                                            \
+    _Pragma("unroll") for (int j_ = 0; j_ < WJ; ++j_)                                                \
+        glds16<0>(tb_ + j_ * RS * 32, wvoff, lb_ + BM * 128 + j_ * RS * 128);                        \
   }
 
   const int X = (l31 >> 1) & 7;
@@ -565,16 +565,27 @@ static hipError_t launch_slab(const ConvArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int CIN, int EPI, int MM = MM_F32, int OUTF = FMT_F32>
-static hipError_t launch_gather(const ConvArgs& a, hipStream_t st) {
-  constexpr size_t lds = (size_t)2 * 256 * 32 * sizeof(float);
-  auto kern = conv3x3_gather_s2_kernel<CIN, EPI, MM, OUTF>;
+template <int CIN, int EPI, int MM, int OUTF, int NW>
+static hipError_t launch_gather_nw(const ConvArgs& a, hipStream_t st) {
+  constexpr int BM = NW * 32;
+  constexpr size_t lds = (size_t)2 * (BM + 128) * 32 * sizeof(float);
+  auto kern = conv3x3_gather_s2_kernel<CIN, EPI, MM, OUTF, NW>;
   static PerDeviceOnce attr;
   hipError_t e = set_lds(kern, lds, attr);
   if (e != hipSuccess) return e;
-  const int tiles_m = (a.M + 127) / 128;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * a.tiles_n * a.groups), dim3(256), lds, st, a);
+  const int tiles_m = (a.M + BM - 1) / BM;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * a.tiles_n * a.groups), dim3(NW * 64), lds, st, a);
   return hipGetLastError();
+}
+
+#ifndef SE3TN_GATHER8_MIN_TILES
+#define SE3TN_GATHER8_MIN_TILES 200   // 256-px tiles (8 waves, 1 workgroup per CU) once they fill most of the 256 CUs
+#endif
+template <int CIN, int EPI, int MM = MM_F32, int OUTF = FMT_F32>
+static hipError_t launch_gather(const ConvArgs& a, hipStream_t st) {
+  const int tiles256 = ((a.M + 255) / 256) * a.tiles_n * a.groups;
+  if (MM == MM_F32 && tiles256 >= SE3TN_GATHER8_MIN_TILES && tiles256 <= 256) return launch_gather_nw<CIN, EPI, MM, OUTF, 8>(a, st);
+  return launch_gather_nw<CIN, EPI, MM, OUTF, 4>(a, st);
 }
 
 template <int EPI, int MM, int OUTF, int RESF>
