@@ -24,14 +24,16 @@ __device__ __forceinline__ void glds16(const float* sbase, unsigned voff_bytes, 
 
 // V 7: product structure incl. the global->LDS DMA of the next K-step's operand tile (8 x 1 KB per wave), source =
 //      the same 32 KB per workgroup every K-step (L2-resident);  V 8: source streams through `big` (HBM / Infinity Cache)
+constexpr bool has_loader(int V) { return V == 12 || V == 13; }
+
 template <int V, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void probe(float* out, const float* seed, int niter, const float* big = nullptr,
-                                                    size_t big_floats = 0) {
+__global__ __launch_bounds__((NW + (has_loader(V) ? 1 : 0)) * 64, 2) void probe(float* out, const float* seed, int niter,
+                                                                             const float* big = nullptr, size_t big_floats = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int ROWS = (NW == 4 ? 256 : 384);          // pixel rows + weight rows per buffer
   constexpr int BUF = ROWS * 32;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int i = tid; i < (V >= 9 ? 3 : 2) * BUF; i += NW * 64) smem[i] = seed[i & 4095];
+  for (int i = tid; i < ((V == 9 || V == 10) ? 3 : 2) * BUF; i += blockDim.x) smem[i] = seed[i & 4095];
   __syncthreads();
   const int l31 = lane & 31, hh = lane >> 5;
   const int wm = NW == 4 ? (wid >> 1) : (wid >> 1), wn = wid & 1;
@@ -67,6 +69,47 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void probe(float* out, co
         GROUP(p0, p1, w0, w1)
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      continue;
+    }
+    if (has_loader(V)) {                 // one extra wave issues ALL the DMA; the compute waves only read LDS and multiply
+      constexpr int NJ = NW == 4 ? 8 : 6;
+      if (wid == NW) {
+        const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float*)smem;
+        const float* src = V == 12 ? big + (size_t)blockIdx.x * 12288
+                                   : big + ((size_t)blockIdx.x * 12288 + (size_t)kt * 12288 * gridDim.x) % (big_floats - 12288);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int w = 0; w < NW; ++w)
+            glds16(src + j * 256 * NW, (unsigned)(lane * 16 + w * 1024),
+                   lds0 + (unsigned)((((kt + 1) & 1) * BUF + j * 256 * NW + w * 256) * 4));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 p0 = PX(g, 0), p1 = PX(g, 1), w0 = WT(g, 0), w1 = WT(g, 1);
+          GROUP(p0, p1, w0, w1)
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    if (V == 11 || V == 14) {            // classical staging: global_load_dwordx4 -> VGPRs -> ds_write_b128
+      constexpr int NJ = NW == 4 ? 8 : 6;
+      const float* src = V == 11 ? big + (size_t)blockIdx.x * 12288
+                                 : big + ((size_t)blockIdx.x * 12288 + (size_t)kt * 12288 * gridDim.x) % (big_floats - 12288);
+      float4 st[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) st[j] = *reinterpret_cast<const float4*>(src + j * 256 * NW + wid * 256 + lane * 4);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 p0 = PX(g, 0), p1 = PX(g, 1), w0 = WT(g, 0), w1 = WT(g, 1);
+        GROUP(p0, p1, w0, w1)
+      }
+      float* dst = smem + ((kt + 1) & 1) * BUF;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(dst + j * 256 * NW + wid * 256 + lane * 4) = st[j];
       __syncthreads();
       continue;
     }
@@ -122,13 +165,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void probe(float* out, co
   }
   float s = 0.f;
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) s += acc[i][j][e];
-  out[blockIdx.x * NW * 64 + tid] = s;
+  if (wid < NW) out[blockIdx.x * NW * 64 + tid] = s;
 }
 
 template <int V, int NW>
 static void run(const char* name, float* out, const float* seed) {
   const int niter = 2000, grid = NW == 4 ? 512 : 256;
-  const size_t lds = (size_t)(NW == 4 ? 256 : 384) * 32 * 4 * (V >= 9 ? 3 : 2);
+  const size_t lds = (size_t)(NW == 4 ? 256 : 384) * 32 * 4 * ((V == 9 || V == 10) ? 3 : 2);
   hipFuncSetAttribute(reinterpret_cast<const void*>(probe<V, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   float* big = nullptr;
   const size_t big_floats = (size_t)256 << 20 >> 2 << 2;   // 1 GiB / 4 ... see below
@@ -138,7 +181,7 @@ static void run(const char* name, float* out, const float* seed) {
   float best = 1e9f;
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((probe<V, NW>), dim3(grid), dim3(NW * 64), lds, 0, out, seed, niter, (const float*)big, (size_t)(1 << 28));
+    hipLaunchKernelGGL((probe<V, NW>), dim3(grid), dim3((NW + (has_loader(V) ? 1 : 0)) * 64), lds, 0, out, seed, niter, (const float*)big, (size_t)(1 << 28));
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -166,6 +209,14 @@ int main() {
   run<6, 4>("4 waves x2/CU  software-pipelined + barrier", out, seed);
   run<7, 4>("4 waves x2/CU  product structure + DMA from L2-resident src", out, seed);
   run<8, 4>("4 waves x2/CU  product structure + DMA streaming 1 GiB", out, seed);
+  run<12, 4>("4+1 waves x2/CU  loader wave issues all DMA, L2-resident src", out, seed);
+  run<13, 4>("4+1 waves x2/CU  loader wave issues all DMA, streaming", out, seed);
+  run<11, 4>("4 waves x2/CU  global_load -> VGPR -> ds_write, L2-resident", out, seed);
+  run<14, 4>("4 waves x2/CU  global_load -> VGPR -> ds_write, streaming", out, seed);
+  run<12, 8>("8+1 waves x1/CU  loader wave issues all DMA, L2-resident src", out, seed);
+  run<13, 8>("8+1 waves x1/CU  loader wave issues all DMA, streaming", out, seed);
+  run<11, 8>("8 waves x1/CU  global_load -> VGPR -> ds_write, L2-resident", out, seed);
+  run<14, 8>("8 waves x1/CU  global_load -> VGPR -> ds_write, streaming", out, seed);
   run<0, 8>("8 waves x1/CU  registers only", out, seed);
   run<9, 8>("8 waves x1/CU  3 buffers, DMA 2 K-steps ahead, L2-resident src", out, seed);
   run<10, 8>("8 waves x1/CU  3 buffers, DMA 2 K-steps ahead, streaming", out, seed);
