@@ -101,6 +101,7 @@ struct se3tn_mesh {
   float *verts = nullptr, *normals = nullptr, *colors = nullptr;
   int* faces = nullptr;
   float4* vwin = nullptr;
+  int* big = nullptr;     // [1 + F] queue of large triangles (raster_big_kernel)
   int V = 0, F = 0;
   // pyrender-style material (se3tn_mesh_set_texture): uv per vertex, RGB mip pyramid, Kd
   float* uv = nullptr;
@@ -609,7 +610,7 @@ int se3tn_mesh_create(se3tn_ctx* c, const float* verts, const float* normals, co
   struct { void** p; const void* src; size_t bytes; } up[] = {
       {(void**)&m->verts, verts, sizeof(float) * 3 * V},     {(void**)&m->normals, normals, sizeof(float) * 3 * V},
       {(void**)&m->colors, colors01, sizeof(float) * 3 * V}, {(void**)&m->faces, faces, sizeof(int) * 3 * F},
-      {(void**)&m->vwin, nullptr, sizeof(float4) * V}};
+      {(void**)&m->vwin, nullptr, sizeof(float4) * V},       {(void**)&m->big, nullptr, sizeof(int) * (1 + (size_t)F)}};
   for (auto& u : up) {
     hipError_t e = hipMalloc(u.p, u.bytes);
     if (e == hipSuccess && u.src) e = hipMemcpy(*u.p, u.src, u.bytes, hipMemcpyHostToDevice);
@@ -659,7 +660,7 @@ int se3tn_mesh_set_texture(se3tn_mesh* m, const float* uv, const uint8_t* rgb, i
 
 void se3tn_mesh_destroy(se3tn_mesh* m) {
   if (!m) return;
-  void* bufs[] = {m->verts, m->normals, m->colors, m->faces, m->vwin, m->uv, m->tex};
+  void* bufs[] = {m->verts, m->normals, m->colors, m->faces, m->vwin, m->big, m->uv, m->tex};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete m;
@@ -672,7 +673,7 @@ int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const 
   if (window[2] <= window[0] || window[3] <= window[1]) return fail(SE3TN_E_ARG, "se3tn_render: empty window");
   RasterArgs a{};
   a.verts = m->verts; a.normals = m->normals; a.colors = m->colors; a.faces = m->faces; a.vwin = m->vwin;
-  a.zbuf = c->zbuf; a.rgb = rgb; a.depth = depth; a.V = m->V; a.F = m->F;
+  a.zbuf = c->zbuf; a.big = m->big; a.rgb = rgb; a.depth = depth; a.V = m->V; a.F = m->F;
   a.rw = RES; a.rh = RES; a.mode = 0;
   for (int i = 0; i < 12; ++i) a.M[i] = (float)ob_in_cam[i];
   a.fx = (float)K[0]; a.fy = (float)K[4]; a.cx = (float)K[2]; a.cy = (float)K[5];
@@ -725,7 +726,7 @@ int se3tn_render_frame(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], 
   }
   RasterArgs a{};
   a.verts = m->verts; a.normals = m->normals; a.colors = m->colors; a.faces = m->faces; a.vwin = m->vwin;
-  a.zbuf = c->zbuf; a.rgb = rgb; a.depth = depth; a.V = m->V; a.F = m->F;
+  a.zbuf = c->zbuf; a.big = m->big; a.rgb = rgb; a.depth = depth; a.V = m->V; a.F = m->F;
   a.rw = W; a.rh = H; a.mode = 1;
   a.uv = m->uv; a.tex = m->tex; a.tw = m->tw; a.th = m->th; a.tlevels = m->tlevels;
   for (int i = 0; i < 16; ++i) a.tex_off[i] = m->tex_off[i];

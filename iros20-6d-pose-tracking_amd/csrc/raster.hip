@@ -35,6 +35,7 @@
 namespace se3tn {
 
 constexpr float R_NEAR = 0.1f, R_FAR = 2.0f;
+constexpr int RASTER_BIG_PX = 256;   // bounding boxes above this many pixels go to raster_big_kernel
 
 __global__ __launch_bounds__(256) void raster_vertex_kernel(const RasterArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -89,6 +90,15 @@ __global__ __launch_bounds__(256) void raster_triangle_kernel(const RasterArgs a
   const float ymin = fminf(v0.y, fminf(v1.y, v2.y)), ymax = fmaxf(v0.y, fmaxf(v1.y, v2.y));
   const int i0 = max(0, (int)floorf(xmin - 0.5f)), i1 = min(a.rw - 1, (int)ceilf(xmax - 0.5f));
   const int j0 = max(0, (int)floorf(ymin - 0.5f)), j1 = min(a.rh - 1, (int)ceilf(ymax - 0.5f));
+  if (i1 < i0 || j1 < j0) return;
+  // a triangle that covers many pixels (coarse mesh, close-up) would serialise this thread: it is queued for
+  // raster_big_kernel, where a whole wave walks its bounding box.  The z-buffer keys make the result independent of
+  // the order in which the queue is filled.
+  if (a.big && (i1 - i0 + 1) * (j1 - j0 + 1) > RASTER_BIG_PX) {
+    const int k = atomicAdd(a.big, 1);
+    a.big[1 + k] = t;
+    return;
+  }
   for (int j = j0; j <= j1; ++j)
     for (int i = i0; i <= i1; ++i) {
       float l0, l1, l2;
@@ -98,6 +108,33 @@ __global__ __launch_bounds__(256) void raster_triangle_kernel(const RasterArgs a
       const unsigned long long key = ((unsigned long long)__float_as_uint(zw) << 32) | (unsigned)t;
       atomicMin(a.zbuf + j * a.rw + i, key);
     }
+}
+
+// one wave per queued triangle, lanes stride over the pixels of its bounding box
+__global__ __launch_bounds__(256) void raster_big_kernel(const RasterArgs a) {
+  const int nbig = a.big[0];
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+  for (int k = wave; k < nbig; k += nwaves) {
+    const int t = a.big[1 + k];
+    const float4 v0 = a.vwin[a.faces[3 * t]];
+    float4 v1 = a.vwin[a.faces[3 * t + 1]], v2 = a.vwin[a.faces[3 * t + 2]];
+    float area = edge_fn(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+    if (area < 0.f) { const float4 tmp = v1; v1 = v2; v2 = tmp; area = -area; }
+    const float xmin = fminf(v0.x, fminf(v1.x, v2.x)), xmax = fmaxf(v0.x, fmaxf(v1.x, v2.x));
+    const float ymin = fminf(v0.y, fminf(v1.y, v2.y)), ymax = fmaxf(v0.y, fmaxf(v1.y, v2.y));
+    const int i0 = max(0, (int)floorf(xmin - 0.5f)), i1 = min(a.rw - 1, (int)ceilf(xmax - 0.5f));
+    const int j0 = max(0, (int)floorf(ymin - 0.5f)), j1 = min(a.rh - 1, (int)ceilf(ymax - 0.5f));
+    const int bw = i1 - i0 + 1, npx = bw * (j1 - j0 + 1);
+    for (int q = lane; q < npx; q += 64) {
+      const int j = j0 + q / bw, i = i0 + q % bw;
+      float l0, l1, l2;
+      if (!covers(v0, v1, v2, area, i + 0.5f, j + 0.5f, l0, l1, l2)) continue;
+      const float zw = l0 * v0.z + l1 * v1.z + l2 * v2.z;
+      if (!(zw >= 0.f && zw < 1.f)) continue;
+      const unsigned long long key = ((unsigned long long)__float_as_uint(zw) << 32) | (unsigned)t;
+      atomicMin(a.zbuf + j * a.rw + i, key);
+    }
+  }
 }
 
 // texel (x, y) of mip level l (RGB uint8, levels stored back to back, level l is max(tw >> l, 1) x max(th >> l, 1)); REPEAT wrap
@@ -213,7 +250,12 @@ hipError_t launch_raster(const RasterArgs& a, hipStream_t st) {
   hipError_t e = hipMemsetAsync(a.zbuf, 0xff, sizeof(unsigned long long) * a.rw * a.rh, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(raster_vertex_kernel, dim3((a.V + 255) / 256), dim3(256), 0, st, a);
+  if (a.big) {
+    e = hipMemsetAsync(a.big, 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(raster_triangle_kernel, dim3((a.F + 255) / 256), dim3(256), 0, st, a);
+  if (a.big) hipLaunchKernelGGL(raster_big_kernel, dim3(128), dim3(256), 0, st, a);
   hipLaunchKernelGGL(raster_resolve_kernel, dim3((a.rw * a.rh + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }

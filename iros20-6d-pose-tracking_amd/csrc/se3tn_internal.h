@@ -222,6 +222,7 @@ struct RasterArgs {
   const int* faces;      // [F,3]
   float4* vwin;          // [V] scratch: window-space x, y, depth in [0,1], 1/w
   unsigned long long* zbuf;  // [rw*rh] scratch
+  int* big;              // [1 + F] queue of triangles with large bounding boxes (big[0] = count) or nullptr
   uint8_t* rgb;          // out [rh,rw,3]
   uint16_t* depth;       // out [rh,rw] millimetres
   float M[12];           // ob_in_cv_cam rows 0..2 (R | t)

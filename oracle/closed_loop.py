@@ -35,6 +35,8 @@ def make_tracker(se3, subdiv=5, precision=None):
     from . import raster_oracle as R
     mean, std = Fx.mean_std(0)
     sd = O.make_state_dict(0, head_gain=HEAD_GAIN)
+    for k in ("trans_out.0.bias", "rot_out.0.bias"):     # the FC biases alone would move the pose 1.5 mm per frame
+        sd[k] = sd[k] * 0.1
     mesh = R.icosphere(subdiv, 0.06, 0)                   # 20 * 4^subdiv faces
     trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=OBJECT_WIDTH_MM), mean, std, {"state_dict": sd})
     trk.renderer = se3.HipRenderer(trk.engine, mesh)

@@ -41,7 +41,9 @@ def test_oracle_projection_geometry():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,subdiv,t", [(0, 2, (0.03, -0.02, 0.65)), (1, 3, (-0.05, 0.04, 0.9)), (2, 1, (0.0, 0.0, 0.45))])
+# (3, 0, ...): 20 large triangles, each a bounding box of thousands of pixels: the wave-per-triangle path (raster_big_kernel)
+@pytest.mark.parametrize("seed,subdiv,t", [(0, 2, (0.03, -0.02, 0.65)), (1, 3, (-0.05, 0.04, 0.9)), (2, 1, (0.0, 0.0, 0.45)),
+                                           (3, 0, (0.005, -0.004, 0.3))])
 def test_hip_rasteriser_vs_oracle(se3, seed, subdiv, t):
     m = R.icosphere(subdiv, 0.05, seed)
     eng = se3.Engine(0, 1)
