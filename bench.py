@@ -283,6 +283,28 @@ def main():
             executed_per_pair += convs * 2 * cin * cout * (nf * tiles - 9 * hw * hw)
     executed = executed_per_pair * nb / (conv_ms_avg * 1e-3) / 1e12
     layers = eng.profile_launches(slots - 1)
+    # per-launch view: executed flops of every conv launch over its own HIP-event time (averaged over the recorded steps)
+    per_slot = [dict(eng.profile_launches(s_)) for s_ in range(slots)]
+    spec = {   # name prefix -> (cin, cout, groups, out_hw, winograd-capable)
+        "conv64 A2.conv1": (64, 64, 2, 44, False), "conv64 A2.conv2": (64, 64, 2, 44, False),
+        "conv64 B3.conv1": (64, 64, 1, 44, False), "conv64 B3.conv2": (64, 64, 1, 44, False),
+        "convAB1": (128, 256, 1, 22, False), "convAB2.conv1": (256, 256, 1, 22, True), "convAB2.conv2": (256, 256, 1, 22, True),
+        "trans|rot conv1": (256, 1024, 1, 11, False), "trans|rot conv2.conv1": (512, 512, 2, 11, True),
+        "trans|rot conv2.conv2": (512, 512, 2, 11, True)}
+    per_layer = []
+    for name, _ in layers:
+        key = next((k for k in spec if name.startswith(k)), None)
+        if key is None:
+            continue
+        cin, cout, groups, hw, wcap = spec[key]
+        ms = float(np.mean([d_[name] for d_ in per_slot if name in d_]))
+        if wcap and wino_on:
+            fl = 2.0 * cin * cout * groups * (wino_tile + 2) ** 2 * (-(-hw // wino_tile)) ** 2 * nb
+        else:
+            fl = 2.0 * cin * cout * groups * 9 * hw * hw * nb
+        per_layer.append({"launch": name, "ms": round(ms, 4), "gflop_executed": round(fl / 1e9, 2),
+                          "tflops": round(fl / (ms * 1e-3) / 1e12, 1), "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+    dominant = max(per_layer, key=lambda d_: d_["ms"]) if per_layer else None
     eng.profile_enable(0)
     torch.cuda.synchronize()
     pose_main = poseB.clone()
@@ -376,7 +398,10 @@ def main():
                          "traffic": None,
                          "conv_ms_per_step": round(conv_ms_avg, 4), "all_kernels_ms_per_step": round(float(np.mean(tot_ms)), 4),
                          "timing": "hipEvents around every launch on the launch stream inside the timed region "
-                                   "(last %d steps)" % slots},
+                                   "(last %d steps)" % slots,
+                         # the single longest launch of the family and every launch's own rate (Winograd entries include their
+                         # transform passes in the time)
+                         "dominant_launch": dominant, "launches": per_layer},
             "layers_ms": {n: round(ms, 4) for n, ms in layers},
         }
         if short is not None:
