@@ -150,7 +150,7 @@ static int wino_prepare(se3tn_ctx* c, hipStream_t st) {
 
 extern "C" {
 
-const char* se3tn_version(void) { return "se3tracknet-gfx950 0.3.1 (blob v6)"; }
+const char* se3tn_version(void) { return "se3tracknet-gfx950 0.4.0 (blob v6)"; }
 const char* se3tn_last_error(void) { return g_err.c_str(); }
 
 int se3tn_create(int device, int max_batch, se3tn_ctx** out) {

@@ -27,7 +27,11 @@
 // REPEAT wrap; or the vertex colour), depth returned as linear camera z; Tracker.render_window then crops it with
 // crop_bbox (predict.py:209-213).  Parity with pyrender's shader / a GL driver's texture filtering is unpinned.
 //
-// Three kernels: vertices -> window space; one thread per triangle scatters (depth | triangle id) keys
+// Clipping: fragments are depth-tested against the near / far planes per pixel, so a triangle that crosses the near plane in
+// FRONT of the camera is cut exactly; a triangle with a vertex at or behind the camera plane (z <= 0) is dropped whole, not
+// clipped -- it cannot occur for a tracked object (range 0.3-2 m, radius < 0.3 m).
+//
+// Three kernels (+ raster_big_kernel for triangles with large bounding boxes): vertices -> window space; one thread per triangle scatters (depth | triangle id) keys
 // with 64-bit atomicMin (deterministic z-buffer, ties broken by triangle index); one thread per pixel
 // re-derives the barycentrics of the winning triangle, interpolates and shades.
 #include "se3tn_internal.h"

@@ -83,7 +83,38 @@ int main(int argc, char** argv) {
   int32_t vu[8];
   const double K[9] = {1066.778, 0, 312.9869, 0, 1067.487, 241.3109, 0, 0, 1};
   CHECK(se3tn_compute_bbox(hP, K, 250.0, vu));
-  printf("ok n=%d version=\"%s\" bbox0=(%d,%d)\n", n, se3tn_version(), vu[0], vu[1]);
+  /* live-camera front end and crop_bbox from C: a 64 x 80 depth ramp with holes through se3tn_fill_depth (no blur:
+   * selections only, exact), then its centre window through se3tn_crop_raw */
+  enum { FH = 64, FW = 80 };
+  uint16_t hd[FH * FW], hf[FH * FW];
+  uint8_t hrgb[FH * FW * 3];
+  for (int y = 0; y < FH; ++y)
+    for (int x = 0; x < FW; ++x) {
+      hd[y * FW + x] = (uint16_t)(((x * 7 + y * 3) % 11 == 0) ? 0 : 600 + 3 * x + 2 * y);
+      for (int c = 0; c < 3; ++c) hrgb[(y * FW + x) * 3 + c] = (uint8_t)((x + 2 * y + 5 * c) & 255);
+    }
+  uint16_t *dD, *dF, *dCd;
+  uint8_t *dRgb, *dCr;
+  if (hipMalloc((void**)&dD, sizeof(hd)) || hipMalloc((void**)&dF, sizeof(hd)) || hipMalloc((void**)&dRgb, sizeof(hrgb)) ||
+      hipMalloc((void**)&dCr, 176 * 176 * 3) || hipMalloc((void**)&dCd, 176 * 176 * 2)) return 3;
+  hipMemcpy(dD, hd, sizeof(hd), hipMemcpyHostToDevice);
+  hipMemcpy(dRgb, hrgb, sizeof(hrgb), hipMemcpyHostToDevice);
+  CHECK(se3tn_fill_depth(ctx, dD, FH, FW, 2.0, 0, SE3TN_BLUR_NONE, dF, NULL, NULL));
+  se3tn_crop crop;
+  memset(&crop, 0, sizeof(crop));
+  crop.rgb = dRgb; crop.depth = dF; crop.H = FH; crop.W = FW;
+  crop.left = 10; crop.top = -6; crop.right = 70; crop.bottom = 54;      /* leaves the frame at the top */
+  uint16_t* hc = (uint16_t*)malloc(176 * 176 * 2);
+  CHECK(se3tn_crop_raw(ctx, &crop, dCr, dCd, NULL));
+  if (hipDeviceSynchronize() != hipSuccess) return 3;
+  hipMemcpy(hf, dF, sizeof(hf), hipMemcpyDeviceToHost);
+  hipMemcpy(hc, dCd, 176 * 176 * 2, hipMemcpyDeviceToHost);
+  unsigned long long sum_f = 0, sum_c = 0;
+  int holes = 0;
+  for (int i = 0; i < FH * FW; ++i) { sum_f += hf[i]; holes += hf[i] == 0; }
+  for (int i = 0; i < 176 * 176; ++i) sum_c += hc[i];
+  printf("ok n=%d version=\"%s\" bbox0=(%d,%d) fill_sum=%llu fill_holes=%d crop_sum=%llu\n", n, se3tn_version(), vu[0], vu[1],
+         sum_f, holes, sum_c);
   se3tn_destroy(ctx);
   return 0;
 }

@@ -53,6 +53,17 @@ def test_c_host_matches_oracle(tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert out.stdout.startswith("ok n=2")
+    # se3tn_fill_depth (no blur: exact) and se3tn_crop_raw called from C, against the oracles on the same synthetic frame
+    from oracle import depth_oracle as D
+    yy, xx = np.mgrid[0:64, 0:80]
+    hd = np.where((xx * 7 + yy * 3) % 11 == 0, 0, 600 + 3 * xx + 2 * yy).astype(np.uint16)
+    filled = D.grab_depth(hd, 2.0, False, None)
+    rgb = np.stack([(xx + 2 * yy + 5 * c) & 255 for c in range(3)], -1).astype(np.uint8)
+    bb = np.array([[-6, 10], [54, 10], [-6, 70], [54, 70]])          # (v, u) corners of the window (10, -6, 70, 54)
+    _, crop_d = O.crop_bbox(rgb, filled, bb, (176, 176))
+    fields = dict(tok.split("=") for tok in out.stdout.split() if "=" in tok and not tok.startswith(("version", "bbox0")))
+    assert int(fields["fill_sum"]) == int(filled.astype(np.int64).sum()) and int(fields["fill_holes"]) == int((filled == 0).sum())
+    assert int(fields["crop_sum"]) == int(crop_d.astype(np.int64).sum())
     raw = open(tmp_path / "out.bin", "rb").read()
     trans = np.frombuffer(raw[:n * 12], np.float32).reshape(n, 3)
     rot = np.frombuffer(raw[n * 12:n * 24], np.float32).reshape(n, 3)
