@@ -284,7 +284,17 @@ hipError_t launch_stem(const float* inA, const float* inB, const float* w, const
 // its input keeps explicit bounds.  One thread per (output pixel, 4 channels).
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ in,
                                                             float* __restrict__ out, int total, int split_out) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  // workgroup -> (image, 8-pixel run): consecutive workgroup ids land on different XCDs (id % 8), but output rows p and
+  // p + 1 share the input row 2p + 1 -- so each XCD gets whole images (image = 8 k + xcd): the shared rows are then
+  // re-read from that XCD's own L2 instead of from HBM / Infinity Cache
+  constexpr int WPI = S2 * S2 * 32 / 256;      // 242 workgroups per image
+  int blk = blockIdx.x;
+  const int full = (total / (WPI * 256)) / 8 * 8;          // images covered by the remapped part
+  if (blk < full * WPI) {
+    const int xcd = blk & 7, seq = blk >> 3;
+    blk = ((seq / WPI) * 8 + xcd) * WPI + seq % WPI;
+  }
+  const int idx = blk * 256 + threadIdx.x;
   if (idx >= total) return;
   const int c4 = idx & 31;
   const int pix = idx >> 5;
