@@ -1,0 +1,40 @@
+"""GPU: every batch size around the algorithm / tile-shape switch points against the CPU oracle.
+Switch points of se3tn_infer (n pairs): split-K latency kernels below ~200 big-tile workgroups per layer, Winograd F(4x4)
+fused blocks from n >= 6, 256 x 128 stride-2 tiles while they fill 200..256 CUs (n = 50..68 for the heads, 26..67 for
+convAB1), ragged last tiles at every n that is not a multiple of the tile size."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fixtures as Fx
+from oracle import se3_oracle as O
+
+SIZES = [1, 2, 3, 5, 6, 7, 9, 13, 17, 25, 26, 27, 31, 33, 48, 49, 50, 52, 63, 64, 66, 67, 68, 69, 72]
+
+
+def test_every_switch_point_vs_oracle():
+    import se3tracknet_amd as se3
+    sd = O.make_state_dict(3)
+    m = se3.Se3TrackNet(176, max_batch=72)
+    m.load_state_dict(sd)
+    m.cuda(0)
+    A, B = Fx.net_inputs(77, 72)
+    Ac, Bc = A.cuda(), B.cuda()
+    idx = [0, 35, 71]
+    ref = O.forward(sd, A[idx], B[idx])
+    want = torch.cat([ref["trans_logit"], ref["rot_logit"]], 1)
+    worst = 0.0
+    for n in SIZES:
+        # pairs 0 and n-1 of this call are pairs (0 | 35 | 71) of the full set, depending on how the slice is taken
+        for lo in (0, 72 - n):
+            out = m(Ac[lo:lo + n], Bc[lo:lo + n], return_feature=False)
+            lg = m.engine.logits(n).cpu()
+            for k, gi in enumerate(idx):
+                if lo <= gi < lo + n:
+                    e = float((lg[gi - lo] - want[k]).abs().max())
+                    worst = max(worst, e)
+                    assert e < 1e-4, (n, lo, gi, e)
+            assert torch.isfinite(out["trans"]).all()
+    print("max |d logit| over %d batch sizes: %.2e" % (len(SIZES), worst))
