@@ -80,6 +80,10 @@ def main():
     ap.add_argument("--host-frames", action="store_true",
                     help="PCIe-inclusive variant (never the headline): every step's camera frames start in pinned host "
                          "memory and are uploaded on a copy stream, double-buffered against the previous step's compute")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="lanes of the throughput mode (se3.PipelinedEngine): successive steps alternate over this many HIP "
+                         "streams / activation workspaces, so the HBM-bound passes of one step run under the MFMA-bound kernels "
+                         "of the other; 1 = strictly one step at a time (reported as `single_stream` in any case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed batch")
     ap.add_argument("--track-frames", type=int, default=300, help="closed-loop Tracker.on_track stand-in (0 = skip)")
@@ -115,20 +119,23 @@ def main():
     dist_mod = __import__("importlib").import_module("iros20-6d-pose-tracking_amd.dist")
 
     nb = args.batch
-    eng = se3.Engine(local_rank, nb)
+    lanes = 1 if (args.host_frames or args.gather_every_step) else max(1, args.streams)
+    pe = se3.PipelinedEngine(local_rank, nb, depth=lanes)     # lane 0 is also the single-stream engine of the legs below
+    eng = pe.engines[0]
     sd = O.make_state_dict(0) if rank == 0 else None
     if use_dist:
-        dist_mod.load_weights_everywhere(eng, sd)       # C1: RCCL broadcast of the packed blob
+        blob = dist_mod.load_weights_everywhere(eng, sd)       # C1: RCCL broadcast of the packed blob
+        pe.bind_blob(blob)                                     # every lane reads the same device copy
     else:
-        eng.load_state_dict(sd)
+        pe.load_state_dict(sd)
     mean = np.array([110., 105., 100., 1000., 112., 104., 99., 1010.]); std = np.array([60., 58., 61., 300., 59., 60., 62., 310.])
-    eng.set_normalization(mean, std)
+    pe.set_normalization(mean, std)
     TN, RN = 0.03, 5 * np.pi / 180
-    eng.set_normalizers(TN, RN)
+    pe.set_normalizers(TN, RN)
     if args.precision == "f16x3":
-        eng.set_precision(se3._lib.PREC_F16X3)
+        pe.set_precision(se3._lib.PREC_F16X3)
     if args.winograd is not None or args.winograd_tile:
-        eng.set_winograd(args.winograd if args.winograd is not None else 8, args.winograd_tile)
+        pe.set_winograd(args.winograd if args.winograd is not None else 8, args.winograd_tile)
 
     # ---- synthetic inputs, resident in HBM (seeded per rank) -------------------------------
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -254,6 +261,44 @@ def main():
         dt2 = timed_loop(more)
         return dt2, more, (dt, steps), slots
 
+    # ---- throughput mode: successive steps alternate over the lanes of the PipelinedEngine --------------------------
+    lane_out = [(torch.empty((nb, 3), device=dev), torch.empty((nb, 3), device=dev), torch.empty_like(poseA)) for _ in range(lanes)]
+    last_lane = [0]
+
+    def step_pipelined():
+        e, stream = pe.next_lane()
+        k = pe.engines.index(e)
+        last_lane[0] = k
+        with torch.cuda.stream(stream):
+            cA, cB = make_crops(0)
+            e.preprocess(cA, e.input_buffer_ptr(0))
+            e.preprocess(cB, e.input_buffer_ptr(1))
+            e.infer(e.input_buffer_ptr(0), e.input_buffer_ptr(1), nb, se3.NHWC, lane_out[k][0], lane_out[k][1], poseA, lane_out[k][2])
+
+    def timed_loop_pipelined(steps):
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_pipelined()
+        for st_ in pe.streams:                                 # the collective (and the clock) wait for every lane
+            torch.cuda.current_stream().wait_stream(st_)
+        if use_dist:
+            dist_mod.gather_poses(lane_out[last_lane[0]][2])   # C2, once per timed region as in the single-stream loop
+        torch.cuda.synchronize()
+        local_dt[0] = time.perf_counter() - t0
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - t0
+        if use_dist:
+            t_ = torch.tensor([dtp], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            dtp = float(t_.item())
+        return dtp
+
     for _ in range(args.warmup):
         step()
     dt, steps_timed, short, slots = timed_region(args.steps)
@@ -318,6 +363,25 @@ def main():
                                                   poses, bboxes, mean, std, TN, RN, trans_main, rot_main, pose_main,
                                                   check_pre=(args.stage == "full"))
 
+    # ---- the headline when lanes > 1: the same steps pipelined over the lanes (each step is still one batch of nb pairs) ----
+    pipelined = None
+    if lanes > 1 and args.stage == "full":
+        for _ in range(max(args.warmup, 2 * lanes)):
+            step_pipelined()
+        steps_p = steps_timed if args.exact_steps else int(math.ceil(steps_timed * 1.25))   # also >= 1 s at the higher rate
+        dtp = timed_loop_pipelined(steps_p)
+        pr = [nb * steps_p / local_dt[0]]
+        if use_dist:
+            t = torch.tensor([pr[0]], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allr, t)
+            pr = [float(x.item()) for x in allr]
+        same = all(torch.equal(o[0], trans_main) and torch.equal(o[1], rot_main) and torch.equal(o[2], pose_main) for o in lane_out)
+        pipelined = {"lanes": lanes, "value": round(world * nb * steps_p / dtp, 1), "ms_per_step": round(dtp / steps_p * 1e3, 4),
+                     "steps_timed": steps_p, "timed_seconds": round(dtp, 4), "per_rank_pairs_per_s": [round(v, 1) for v in pr],
+                     "outputs_bit_identical_to_single_stream": bool(same)}
+        assert os.environ.get("SE3TN_NOCHECK") or same, "a lane's outputs differ from the single-stream run"
+
     # second arithmetic mode on the same inputs: timed the same way, reported beside the main value
     other = None
     if args.precision == "f32" and nb >= 32 and args.stage == "full" and not os.environ.get("SE3TN_NO_ALT"):
@@ -366,21 +430,32 @@ def main():
     assert os.environ.get("SE3TN_NOCHECK") or not eng.overflow(), "f16x3 range guard fired"
 
     if rank == 0:
-        value = world * nb * steps_timed / dt
+        value_single = world * nb * steps_timed / dt
+        value = pipelined["value"] if pipelined else value_single
         out = {
             "metric": "RGB-D pair inferences/sec (176x176)", "value": round(value, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / steps_timed * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": pipelined["ms_per_step"] if pipelined else round(dt / steps_timed * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "steps_timed": steps_timed, "timed_seconds": round(dt, 4),
+            "steps_timed": pipelined["steps_timed"] if pipelined else steps_timed,
+            "timed_seconds": pipelined["timed_seconds"] if pipelined else round(dt, 4),
+            # `value`: K complete steps of one batch each, successive steps alternating over `lanes` HIP streams / activation
+            # workspaces (PipelinedEngine) -- throughput of the job, not 1 / latency of a step.  `single_stream`: the same K
+            # steps strictly one after the other on one stream; the roofline / layers_ms blocks are measured in THAT region
+            # (kernel durations undisturbed by a concurrent lane).
+            "steps_in_flight": lanes if pipelined else 1,
+            "single_stream": {"value": round(value_single, 1), "ms_per_step": round(dt / steps_timed * 1e3, 4),
+                              "timed_seconds": round(dt, 4), "steps_timed": steps_timed},
             "config": {"workload": "configs[1]: batch=%d synthetic 176x176 RGB-D pairs per GPU, random-init Se3TrackNet "
                                    "(reference state_dict surface), stage=%s" % (nb, args.stage),
                        "pairs_per_gpu": nb, "global_batch": world * nb, "stage": args.stage,
                        "frames": "pinned host memory, uploaded per step (PCIe-inclusive)" if args.host_frames else "resident in HBM",
-                       "parallelism": "frame-sharded x%d, RCCL weight broadcast at start-up, pose all-gather %s" %
-                                      (world, "every step (overlapped)" if args.gather_every_step else "once per timed region")},
+                       "parallelism": "frame-sharded x%d, RCCL weight broadcast at start-up, pose all-gather %s; per GPU the steps "
+                                      "alternate over %d HIP stream(s)" %
+                                      (world, "every step (overlapped)" if args.gather_every_step else "once per timed region", lanes)},
             "rccl_ranks": dist.get_world_size() if use_dist else 1,
-            "per_rank_pairs_per_s": [round(v, 1) for v in per_rank],
+            "per_rank_pairs_per_s": pipelined["per_rank_pairs_per_s"] if pipelined else [round(v, 1) for v in per_rank],
             "tflops_total": round(value * FLOP_PER_PAIR / 1e12, 2),
             "roofline": {"bound": "mfma",
                          "kernel": "3x3 conv family, 10 convs/step on exact-f32 v_mfma_f32_32x32x2_f32: direct implicit GEMM "
@@ -404,12 +479,14 @@ def main():
                          "dominant_launch": dominant, "launches": per_layer},
             "layers_ms": {n: round(ms, 4) for n, ms in layers},
         }
+        if pipelined:
+            out["pipelined"] = pipelined
         if short is not None:
             out["requested_steps_region"] = {"steps": short[1], "seconds": round(short[0], 4),
                                              "ms_per_step": round(short[0] / short[1] * 1e3, 4),
                                              "value": round(world * nb * short[1] / short[0], 1),
-                                             "note": "the --steps region was shorter than %.1f s; `value` is from the longer "
-                                                     "region of steps_timed steps timed right after it" % MIN_TIMED_SECONDS}
+                                             "note": "the --steps region (single stream) was shorter than %.1f s; `single_stream` and "
+                                                     "`value` come from regions of steps_timed steps timed right after it" % MIN_TIMED_SECONDS}
         if parity is not None:
             parity.pop("_oracle", None)
             out["parity"] = parity

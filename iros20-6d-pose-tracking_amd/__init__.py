@@ -6,7 +6,7 @@ Public surface mirrors the reference's for this path: ``Tracker`` (predict.py:12
 libse3tracknet.so (hand-written HIP, C ABI in include/se3tracknet.h); importing this package
 without the built library raises ImportError -- there is no fallback path."""
 from . import _lib
-from .engine import Engine, NCHW, NHWC, compute_bbox as compute_bbox_c, pack_crops, pose_update_host
+from .engine import Engine, PipelinedEngine, NCHW, NHWC, compute_bbox as compute_bbox_c, pack_crops, pose_update_host
 from .se3_tracknet import Se3TrackNet
 from .tracker import Tracker
 from .utils import compute_bbox, crop_window
@@ -16,5 +16,5 @@ from .live import LiveTracker, quaternion_from_matrix
 
 _lib.load()
 
-__all__ = ["Engine", "Se3TrackNet", "Tracker", "compute_bbox", "crop_window", "pack_crops", "pose_update_host", "NCHW", "NHWC",
+__all__ = ["Engine", "PipelinedEngine", "Se3TrackNet", "Tracker", "compute_bbox", "crop_window", "pack_crops", "pose_update_host", "NCHW", "NHWC",
            "metrics", "sequence", "HipRenderer", "LiveTracker", "quaternion_from_matrix"]

@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/ktrace_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-SE3TN_NOCHECK=1 SE3TN_NO_ALT=${NOALT:-1} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-parity --track-frames 0 --exact-steps "$@" > $OUT/bench.json 2> $OUT/trace.err
+SE3TN_NOCHECK=1 SE3TN_NO_ALT=${NOALT:-1} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-parity --track-frames 0 --exact-steps --streams 1 "$@" > $OUT/bench.json 2> $OUT/trace.err
 F=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 python - "$F" <<'PY'
 import csv,sys

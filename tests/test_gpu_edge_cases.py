@@ -289,3 +289,34 @@ def test_large_batch_192_matches_single_pairs(se3):
     fast = m(A, B, return_feature=False)
     assert not m.engine.overflow()
     assert float((fast["trans"] - t).abs().max()) < 2e-5 and float((fast["rot"] - r).abs().max()) < 2e-5
+
+
+def test_pipelined_engine_lanes_share_weights_and_match_single_engine(se3):
+    """PipelinedEngine: two lanes (contexts + streams) on one weight blob; batches alternate over the lanes; every
+    lane's result is bit-identical to a plain Engine's."""
+    import torch
+    from oracle import se3_oracle as O
+    sd = O.make_state_dict(5)
+    n = 8
+    A, B = Fx.net_inputs(41, 3 * n)
+    ref = se3.Engine(0, n)
+    ref.load_state_dict(sd)
+    pe = se3.PipelinedEngine(0, n, depth=2)
+    pe.load_state_dict(sd)
+    pe.set_normalizers(0.03, 5 * np.pi / 180)
+    assert pe.engines[0]._blob is pe.engines[1]._blob          # one device copy of the weights
+    outs, want = [], []
+    Ac, Bc = A.cuda(), B.cuda()
+    torch.cuda.synchronize()
+    for k in range(3):
+        eng, stream = pe.next_lane()
+        t = torch.empty((n, 3), device="cuda"); r = torch.empty((n, 3), device="cuda")
+        with torch.cuda.stream(stream):
+            eng.infer(Ac[k * n:(k + 1) * n], Bc[k * n:(k + 1) * n], n, se3.NCHW, t, r)
+        outs.append((t, r))
+    pe.synchronize()
+    for k in range(3):
+        t = torch.empty((n, 3), device="cuda"); r = torch.empty((n, 3), device="cuda")
+        ref.infer(Ac[k * n:(k + 1) * n], Bc[k * n:(k + 1) * n], n, se3.NCHW, t, r)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[k][0], t) and torch.equal(outs[k][1], r)
