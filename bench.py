@@ -275,6 +275,20 @@ def main():
             e.preprocess(cB, e.input_buffer_ptr(1))
             e.infer(e.input_buffer_ptr(0), e.input_buffer_ptr(1), nb, se3.NHWC, lane_out[k][0], lane_out[k][1], poseA, lane_out[k][2])
 
+    def verify_pipelined(steps, want):
+        """Untimed: `steps` pipelined steps queued back to back, the outputs of EVERY step kept (cloned on its own
+        stream) and compared with the single-stream results `want` = (trans, rot, pose).  Returns the number of
+        steps whose outputs are not bit-identical."""
+        torch.cuda.synchronize()
+        kept = []
+        for _ in range(steps):
+            step_pipelined()
+            k = last_lane[0]
+            with torch.cuda.stream(pe.streams[k]):
+                kept.append(tuple(x.clone() for x in lane_out[k]))
+        torch.cuda.synchronize()
+        return sum(0 if all(torch.equal(a, b) for a, b in zip(o, want)) else 1 for o in kept)
+
     def timed_loop_pipelined(steps):
         torch.cuda.synchronize()
         if use_dist:
@@ -377,9 +391,13 @@ def main():
             dist.all_gather(allr, t)
             pr = [float(x.item()) for x in allr]
         same = all(torch.equal(o[0], trans_main) and torch.equal(o[1], rot_main) and torch.equal(o[2], pose_main) for o in lane_out)
+        n_verify = 16 * lanes
+        n_bad = verify_pipelined(n_verify, (trans_main, rot_main, pose_main))
+        same = same and n_bad == 0
         pipelined = {"lanes": lanes, "value": round(world * nb * steps_p / dtp, 1), "ms_per_step": round(dtp / steps_p * 1e3, 4),
                      "steps_timed": steps_p, "timed_seconds": round(dtp, 4), "per_rank_pairs_per_s": [round(v, 1) for v in pr],
-                     "outputs_bit_identical_to_single_stream": bool(same)}
+                     "outputs_bit_identical_to_single_stream": bool(same),
+                     "verified_steps": n_verify, "verified_steps_differing": n_bad}
         assert os.environ.get("SE3TN_NOCHECK") or same, "a lane's outputs differ from the single-stream run"
 
     # second arithmetic mode on the same inputs: timed the same way, reported beside the main value
@@ -404,6 +422,21 @@ def main():
         if parity is not None:   # the same oracle outputs, this mode's device results
             other["parity"] = compare_with_oracle(np, parity["_oracle"], trans.cpu().numpy(), rot.cpu().numpy(),
                                                   poseB.cpu().numpy().reshape(nb, 4, 4))
+        if lanes > 1:            # and pipelined over the lanes like the headline
+            t16, r16, p16 = trans.clone(), rot.clone(), poseB.clone()
+            pe.set_precision(se3._lib.PREC_F16X3)
+            for _ in range(max(args.warmup, 2 * lanes)):
+                step_pipelined()
+            dt2p = timed_loop_pipelined(steps_timed)
+            other["pipelined_value"] = round(world * nb * steps_timed / dt2p, 1)
+            other["pipelined_ms_per_step"] = round(dt2p / steps_timed * 1e3, 4)
+            n_bad16 = verify_pipelined(16 * lanes, (t16, r16, p16))
+            other["pipelined_outputs_bit_identical"] = bool(n_bad16 == 0 and all(
+                torch.equal(o[0], t16) and torch.equal(o[1], r16) and torch.equal(o[2], p16) for o in lane_out))
+            other["pipelined_verified_steps"] = 16 * lanes
+            other["pipelined_verified_steps_differing"] = n_bad16
+            other["range_guard_fired"] = bool(other["range_guard_fired"] or any(e_.overflow() for e_ in pe.engines))
+            pe.set_precision(se3._lib.PREC_F32)
         eng.set_precision(se3._lib.PREC_F32)
     # and the same float32 run with the Winograd layers switched back to the direct kernels
     direct = None

@@ -320,3 +320,49 @@ def test_pipelined_engine_lanes_share_weights_and_match_single_engine(se3):
         ref.infer(Ac[k * n:(k + 1) * n], Bc[k * n:(k + 1) * n], n, se3.NCHW, t, r)
         torch.cuda.synchronize()
         assert torch.equal(outs[k][0], t) and torch.equal(outs[k][1], r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "direct"])
+@pytest.mark.parametrize("n", [64, 8])
+def test_two_contexts_queued_on_two_streams_are_bit_identical_to_one(se3, precision, n):
+    """Throughput mode under load: two contexts, two streams, the infers of a whole round queued back to back
+    with no host synchronisation in between; every launch must reproduce the single-context logits bit for
+    bit.  Regression test for the average-pool / FC tail: with two f16x3 contexts in flight its counted
+    `s_waitcnt vmcnt(N)` accumulation read stale registers (wrong sums in 40-85 % of the launches);
+    kernels_misc.hip now drains the loads of a batch completely before the first add."""
+    import torch
+    from oracle import se3_oracle as O
+    sd = O.make_state_dict(0)
+    A, B = Fx.net_inputs(5, n)
+    Ac, Bc = A.cuda(), B.cuda()
+    engines = []
+    for _ in range(2):
+        e = se3.Engine(0, n)
+        e.load_state_dict(sd)
+        if precision == "f16x3":
+            e.set_precision(se3._lib.PREC_F16X3)
+        elif precision == "direct":
+            e.set_winograd(0)
+        engines.append(e)
+    t = torch.empty((n, 3), device="cuda"); r = torch.empty((n, 3), device="cuda")
+    refs = []
+    for e in engines:
+        e.infer(Ac, Bc, n, se3.NCHW, t, r)
+        torch.cuda.synchronize()
+        refs.append(e.logits(n).clone())
+    assert torch.equal(refs[0], refs[1])
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    rounds, per_round = 4, 8
+    outs = [(torch.empty((n, 3), device="cuda"), torch.empty((n, 3), device="cuda")) for _ in range(per_round)]
+    bad = []
+    for k in range(rounds):
+        torch.cuda.synchronize()
+        caps = []
+        for i in range(per_round):
+            with torch.cuda.stream(streams[i % 2]):
+                engines[i % 2].infer(Ac, Bc, n, se3.NCHW, outs[i][0], outs[i][1])
+                caps.append(engines[i % 2].logits(n))
+        torch.cuda.synchronize()
+        bad += [(k, i, int((lg != refs[0]).any(1).sum())) for i, lg in enumerate(caps) if not torch.equal(lg, refs[0])]
+    assert not bad, "launches (round, index, wrong rows) that differ from the single-context result: %s" % bad
