@@ -509,7 +509,13 @@ def main():
                                    "(last %d steps)" % slots,
                          # the single longest launch of the family and every launch's own rate (Winograd entries include their
                          # transform passes in the time)
-                         "dominant_launch": dominant, "launches": per_layer},
+                         "dominant_launch": dominant, "launches": per_layer,
+                         # whole-step view: every MFMA flop a step executes (the ten 3x3 convs as run + the two 7x7 stems,
+                         # 194,281,472 MAC per pair) over the WALL time of a step, single-stream and pipelined
+                         "whole_step": {"flop_per_step_executed": executed_per_pair * nb + 2 * 194281472 * nb,
+                                        "frac_single_stream": round((executed_per_pair + 2 * 194281472) * nb / (dt / steps_timed) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                        "frac_pipelined": (round((executed_per_pair + 2 * 194281472) * nb / (pipelined["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                                                           if pipelined else None)}},
             "layers_ms": {n: round(ms, 4) for n, ms in layers},
         }
         if pipelined:

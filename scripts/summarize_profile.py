@@ -21,7 +21,10 @@ lines = []
 stats = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
 ours = [r for r in stats if "se3tn::" in r["Name"]]
 tot = sum(float(r["TotalDurationNs"]) for r in ours)
-lines.append("## rocprofv3 --kernel-trace --stats (python bench.py --steps 20 --warmup 3)\n")
+cmd = "python bench.py --steps 20 --warmup 3"
+if os.path.exists(os.path.join(src, "cmd.txt")):
+    cmd = open(os.path.join(src, "cmd.txt")).read().strip()
+lines.append("## rocprofv3 --kernel-trace --stats (%s)\n" % cmd)
 lines.append("| kernel | calls | avg us | min us | max us | % of se3tn time |\n|---|---|---|---|---|---|")
 for r in ours:
     lines.append("| %s | %s | %.1f | %.1f | %.1f | %.2f |" % (
