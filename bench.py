@@ -115,7 +115,20 @@ def main():
     use_dist = world > 1 or (os.environ.get("SE3TN_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        # RCCL prints its version banner on STDOUT when the communicator is created; stdout carries exactly one JSON
+        # line, so file descriptor 1 points at stderr until the communicator exists (first collective below)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     dist_mod = __import__("importlib").import_module("iros20-6d-pose-tracking_amd.dist")
 
     nb = args.batch
