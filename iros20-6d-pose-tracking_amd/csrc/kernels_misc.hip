@@ -10,6 +10,10 @@
 #include "se3tn_internal.h"
 #include "pose_device.h"
 
+#ifndef SE3TN_TAIL_COUNTED
+#define SE3TN_TAIL_COUNTED 0
+#endif
+
 namespace se3tn {
 
 // f16x3 mode: a network-input pixel (R,G,B,D) is stored as 4 x f16 hi | 4 x f16 lo in the same 16 bytes
@@ -166,6 +170,13 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ hea
   // stream (PipelinedEngine) that form read stale registers in lanes 48-63 of the waves (wrong sums in
   // 40-85 % of the launches, measured; the rows in memory were correct).  With the
   // full drain the same schedule is bit-exact in every launch; the order of the additions is unchanged.
+#if SE3TN_TAIL_COUNTED   // A/B switch: the loop as first written (reproduces the wrong sums, scripts/build_variant.sh)
+#pragma unroll 13
+  for (int p = 0; p < PP; ++p) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)p * 1024);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+#else
   static_assert(PP == 13 * 13, "batches of 13 rows");
 #pragma unroll 1
   for (int p0 = 0; p0 < PP; p0 += 13) {
@@ -179,6 +190,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ hea
 #pragma unroll
     for (int q = 0; q < 13; ++q) { s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w; }
   }
+#endif
   const float inv = (float)(S4 * S4);
   s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv;
   const int hd = t >> 7;            // 0 trans, 1 rot

@@ -7,7 +7,7 @@ OUT=/tmp/variants/$NAME
 mkdir -p $OUT /root/repo/variants
 cd $SRC
 for f in api.cpp weights.cpp; do
-  [ -f $SRC/build/$f.o ] && cp $SRC/build/$f.o $OUT/$f.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result $FLAGS -x hip -c $f -o $OUT/$f.o &
 done
 for f in conv3x3_mfma.hip wino_mfma.hip stem7x7_mfma.hip kernels_misc.hip raster.hip depth_fill.hip; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result $FLAGS -c $f -o $OUT/$f.o &
