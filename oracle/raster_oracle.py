@@ -4,7 +4,10 @@ Written as the literal GL pipeline -- the reference's own matrices (update_cam_m
 NDC -> window transform, pixel-centre sampling with the top-left rule, LESS depth test, no face culling
 (set_cull_face only selects glCullFace; GL_CULL_FACE is never enabled), perspective-correct varyings, the
 fragment shader (:54-76), bottom-up read-back and the depth linearisation (:160-169).
-PARITY UNPINNED: no OpenGL implementation is available offline to compare against."""
+PARITY UNPINNED against an OpenGL implementation (none is available offline).  What IS pinned, independently of this
+file: the geometry -- projection, y-flip, window scaling, row order, depth linearisation -- against the analytic
+ray-sphere intersection (tests/test_renderer.py: test_oracle_vs_analytic_sphere, and the same check on the HIP kernels);
+the shading and GL's fill rules are not."""
 import numpy as np
 
 

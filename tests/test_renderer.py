@@ -197,3 +197,86 @@ def test_tracker_pyrenderer_route(se3, tmp_path):
     P1 = trk.on_track(P0, rgb, depth)
     want, _ = O.on_track(sd, P0, rgb, depth, rgbA, depthA, Fx.K_YCB, 150.0, mean, std)
     assert np.abs(P1 - want).max() < 1e-5
+
+
+# ---- an independent geometric pin: a finely tessellated sphere against the analytic ray-sphere intersection ----------
+def _analytic_sphere_window(P, K, win, res, radius):
+    """Depth (metres, camera z) a perfect sphere of `radius` at P[:3,3] has at the centre of every pixel of the
+    res x res window render, and the ray discriminant (>0: the ray hits).  Window convention of predict.py:201-207:
+    win = (left, top, right, bottom) in (u, cy - fy y/z); image rows count down from `bottom`."""
+    left, top, right, bottom = win
+    i = np.arange(res) + 0.5
+    u = left + i * (right - left) / res
+    vflip = bottom - i * (bottom - top) / res
+    dx = (u - K[0, 2]) / K[0, 0]
+    dy = (K[1, 2] - vflip) / K[1, 1]
+    return _ray_sphere(dx[None, :], dy[:, None], P[:3, 3], radius)
+
+
+def _analytic_sphere_frame(P, K, W, H, radius):
+    """The same for the full-frame (pyrender) route: pixel (row j, column i) looks along ((i+.5-cx)/fx, (j+.5-cy)/fy, 1)."""
+    dx = (np.arange(W) + 0.5 - K[0, 2]) / K[0, 0]
+    dy = (np.arange(H) + 0.5 - K[1, 2]) / K[1, 1]
+    return _ray_sphere(dx[None, :], dy[:, None], P[:3, 3], radius)
+
+
+def _ray_sphere(dx, dy, c, radius):
+    a = dx * dx + dy * dy + 1.0                      # |d|^2 with d = (dx, dy, 1): the parameter t IS the camera-space z
+    b = dx * c[0] + dy * c[1] + c[2]
+    disc = b * b - a * (c @ c - radius * radius)
+    t = (b - np.sqrt(np.maximum(disc, 0.0))) / a
+    return t, disc / (a * radius * radius)           # normalised discriminant: ~ (1 - (miss distance / radius)^2)
+
+
+def _check_against_sphere(depth_mm, z, ndisc, what):
+    hit = ndisc > 0
+    inner = ndisc > 0.12                             # a few pixels inside the silhouette: depth is steep at the rim
+    outer = ndisc < -0.12
+    assert (depth_mm[inner] > 0).all(), what + ": hole inside the analytic silhouette"
+    assert (depth_mm[outer] == 0).all(), what + ": coverage outside the analytic silhouette"
+    area, want = int((depth_mm > 0).sum()), int(hit.sum())
+    assert abs(area - want) <= 0.01 * want + 8, (what, area, want)
+    err = depth_mm[inner].astype(np.float64) - z[inner] * 1000.0
+    # uint16 truncation (-1 .. 0) of a surface inscribed in the sphere: the facets lie <= 0.05 mm inside it at this
+    # tessellation, seen along the ray up to 1 / 0.35 times that at the edge of `inner`
+    assert err.min() > -1.0 - 1e-3 and err.max() < 0.25, (what, err.min(), err.max())
+
+
+def test_oracle_vs_analytic_sphere():
+    """The CPU restatement of the GL pipeline (window render and full-frame render) against geometry it does not
+    share any code with: projection, y-flip, window scaling, row order and depth linearisation all enter."""
+    radius = 0.06
+    m = R.icosphere(4, radius, 0)                    # 5120 faces
+    P = np.eye(4); P[:3, 3] = (0.03, -0.02, 0.7)
+    win = (250, 160, 420, 330)
+    _, depth = R.render(*_mesh_args(m), P, Fx.K_YCB, win)
+    z, nd = _analytic_sphere_window(P, Fx.K_YCB, win, 176, radius)
+    _check_against_sphere(depth, z, nd, "oracle window render")
+    H, W = 120, 160
+    K = np.array([[266.7, 0, 78.2], [0, 266.9, 60.3], [0, 0, 1.0]])
+    P2 = np.eye(4); P2[:3, 3] = (0.01, -0.02, 0.45)
+    _, depth2 = R.render_frame(m["vertices"].astype(np.float32), (m["colors"] / 255.0).astype(np.float32), m["faces"], P2, K, W, H)
+    z2, nd2 = _analytic_sphere_frame(P2, K, W, H, radius)
+    _check_against_sphere(depth2, z2, nd2, "oracle full-frame render")
+
+
+@pytest.mark.gpu
+def test_hip_rasteriser_vs_analytic_sphere(se3):
+    """The HIP rasteriser (both routes) against the analytic sphere: an oracle-independent check of K5."""
+    radius = 0.06
+    m = R.icosphere(5, radius, 0)                    # 20480 faces
+    eng = se3.Engine(0, 1)
+    P = Fx.pose(2, (0.03, -0.02, 0.7))               # rotated: the sphere's silhouette does not care
+    ren = se3.HipRenderer(eng, m)
+    win = se3.HipRenderer.gl_window(P, Fx.K_YCB, 150.0)
+    _, depth = ren.render(P, Fx.K_YCB, win)
+    z, nd = _analytic_sphere_window(P, Fx.K_YCB, win, 176, radius)
+    _check_against_sphere(depth, z, nd, "HIP window render")
+    H, W = 120, 160
+    K = np.array([[266.7, 0, 78.2], [0, 266.9, 60.3], [0, 0, 1.0]])
+    P2 = Fx.pose(3, (0.01, -0.02, 0.45))
+    ren2 = se3.HipRenderer(eng, dict(vertices=m["vertices"], faces=m["faces"], colors=m["colors"], kd=(1.0, 1.0, 1.0)),
+                           mode="pyrender", frame_size=(H, W))
+    _, depth2 = ren2.render_frame(P2, K)
+    z2, nd2 = _analytic_sphere_frame(P2, K, W, H, radius)
+    _check_against_sphere(depth2, z2, nd2, "HIP full-frame render")
