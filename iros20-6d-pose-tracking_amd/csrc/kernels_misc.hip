@@ -10,10 +10,6 @@
 #include "se3tn_internal.h"
 #include "pose_device.h"
 
-#ifndef SE3TN_TAIL_COUNTED
-#define SE3TN_TAIL_COUNTED 0
-#endif
-
 namespace se3tn {
 
 // f16x3 mode: a network-input pixel (R,G,B,D) is stored as 4 x f16 hi | 4 x f16 lo in the same 16 bytes
@@ -164,33 +160,15 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ hea
   constexpr int PP = (S4 + 2) * (S4 + 2);
   const float* src = head + (size_t)n * PP * 1024 + t * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  // 13 batches of 13 rows: all 13 loads in flight, then a FULL drain (vmcnt(0)) before the first add.
-  // The plain `for p: s += row[p]` loop compiles to counted waits (vmcnt(12), vmcnt(11), ...) each followed
-  // at once by the add that consumes the returned row; with a second f16x3 context running on another
-  // stream (PipelinedEngine) that form read stale registers in lanes 48-63 of the waves (wrong sums in
-  // 40-85 % of the launches, measured; the rows in memory were correct).  With the
-  // full drain the same schedule is bit-exact in every launch; the order of the additions is unchanged.
-#if SE3TN_TAIL_COUNTED   // A/B switch: the loop as first written (reproduces the wrong sums, scripts/build_variant.sh)
+  // History: for this loop hipcc once kept the (x, y) sums swapped in their register pair and added
+  // with `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]`; on gfx950 that form returns wrong lanes 48-63 while another kernel's waves
+  // issue v_mfma_f32_32x32x16_f16 on the same CU (two f16x3 contexts in flight: wrong sums in 40-85 % of the launches).  This file is
+  // therefore compiled without packed-float32 instructions (Makefile), and scripts/isa_lint.py checks the whole library for the form.
 #pragma unroll 13
   for (int p = 0; p < PP; ++p) {
     const float4 v = *reinterpret_cast<const float4*>(src + (size_t)p * 1024);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
-#else
-  static_assert(PP == 13 * 13, "batches of 13 rows");
-#pragma unroll 1
-  for (int p0 = 0; p0 < PP; p0 += 13) {
-    float4 v[13];
-#pragma unroll
-    for (int q = 0; q < 13; ++q) v[q] = *reinterpret_cast<const float4*>(src + (size_t)(p0 + q) * 1024);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int q = 0; q < 13; ++q)  // ties every add to the drain (the compiler may not hoist it above the wait)
-      asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
-#pragma unroll
-    for (int q = 0; q < 13; ++q) { s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w; }
-  }
-#endif
   const float inv = (float)(S4 * S4);
   s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv;
   const int hd = t >> 7;            // 0 trans, 1 rot
