@@ -22,6 +22,7 @@ The JSON line carries, besides the contract fields:
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--stage full|net]
 """
 import argparse
+import contextlib
 import json
 import math
 import os
@@ -44,7 +45,7 @@ def self_launch(args):
     """`python bench.py --gpus N` outside a launcher: become `torch.distributed.run --nproc-per-node N bench.py ...`."""
     import torch
     ndev = torch.cuda.device_count()
-    if ndev < args.gpus:
+    if ndev < args.gpus and not args.dry_run_gloo:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this box -- N=%d is UNMEASURED here "
                          "(no extrapolation)" % (args.gpus, ndev, args.gpus))
     with socket.socket() as s:
@@ -91,6 +92,10 @@ def main():
                     help="never extend the timed region beyond --steps (default: a region shorter than 1 s is re-run "
                          "with enough steps and BOTH are reported)")
     ap.add_argument("--layers", action="store_true", help="print the per-launch time breakdown to stderr")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="NOT a measurement: the same self-launch, rank logic, barriers, weight-blob broadcast (the real packed "
+                         "blob), pose all-gather and single JSON line on CPU with the gloo backend and every kernel stubbed out "
+                         "(tests/test_bench_launch.py: the N > 1 code path must have run somewhere before it meets RCCL)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,10 +112,21 @@ def main():
     import se3tracknet_amd as se3
     from oracle import se3_oracle as O  # weights generator, and the CHECKER of the parity / cpu_baseline / track blocks
 
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit("rank %d: no GPU %d on this box (device_count = %d)" % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+    DRY = args.dry_run_gloo
+    if DRY:
+        dev = "cpu"
+        sync = lambda: None                                            # noqa: E731
+        stream_ctx = lambda stream: contextlib.nullcontext()           # noqa: E731
+        args.no_parity = args.no_cpu_baseline = True
+        args.track_frames = 0
+        os.environ["SE3TN_NO_ALT"] = "1"
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("rank %d: no GPU %d on this box (device_count = %d)" % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = "cuda:%d" % local_rank
+        sync = torch.cuda.synchronize
+        stream_ctx = torch.cuda.stream
     # SE3TN_FORCE_DIST=1: run the RCCL code path (weight broadcast, pose all-gather) even at world 1
     use_dist = world > 1 or (os.environ.get("SE3TN_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
@@ -121,10 +137,13 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device(dev))
+            if DRY:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device(dev))
             warm = torch.zeros(1, device=dev)
             dist.all_reduce(warm)
-            torch.cuda.synchronize()
+            sync()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
@@ -133,11 +152,12 @@ def main():
 
     nb = args.batch
     lanes = 1 if (args.host_frames or args.gather_every_step) else max(1, args.streams)
-    pe = se3.PipelinedEngine(local_rank, nb, depth=lanes)     # lane 0 is also the single-stream engine of the legs below
+    # lane 0 is also the single-stream engine of the legs below
+    pe = DryPipelinedEngine(se3, rank, nb, lanes) if DRY else se3.PipelinedEngine(local_rank, nb, depth=lanes)
     eng = pe.engines[0]
     sd = O.make_state_dict(0) if rank == 0 else None
     if use_dist:
-        blob = dist_mod.load_weights_everywhere(eng, sd)       # C1: RCCL broadcast of the packed blob
+        blob = dist_mod.load_weights_everywhere(eng, sd, device=dev)   # C1: RCCL broadcast of the packed blob
         pe.bind_blob(blob)                                     # every lane reads the same device copy
     else:
         pe.load_state_dict(sd)
@@ -187,6 +207,8 @@ def main():
             uploaded[k].record(copy_stream)
 
     def make_crops(k=0):   # per step, like a tracker would: 2 x nb descriptors, vectorised (no per-crop Python)
+        if DRY:
+            return None, None
         return (se3.pack_crops(rend_rgb, rend_d, windowsA, z_mm, 0),
                 se3.pack_crops(frame_sets[k][0], frame_sets[k][1], windowsB, z_mm, 1))
     cropsA, cropsB = make_crops()
@@ -237,21 +259,22 @@ def main():
             pending.pop(0)[1].wait()
 
     local_dt = [0.0]
+    min_timed = 0.02 if DRY else MIN_TIMED_SECONDS
 
     def timed_loop(steps):
-        torch.cuda.synchronize()
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         drain()
-        torch.cuda.synchronize()
+        sync()
         local_dt[0] = time.perf_counter() - t0      # this rank alone (before the closing barrier)
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         dt = time.perf_counter() - t0
         if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -266,9 +289,9 @@ def main():
         slots = min(steps, 64)
         eng.profile_enable(slots)
         dt = timed_loop(steps)
-        if args.exact_steps or dt >= MIN_TIMED_SECONDS:
+        if args.exact_steps or dt >= min_timed:
             return dt, steps, None, slots
-        more = min(20000, int(math.ceil(steps * MIN_TIMED_SECONDS * 1.1 / dt)))
+        more = min(20000, int(math.ceil(steps * min_timed * 1.1 / dt)))
         slots = min(more, 64)
         eng.profile_enable(slots)
         dt2 = timed_loop(more)
@@ -282,7 +305,7 @@ def main():
         e, stream = pe.next_lane()
         k = pe.engines.index(e)
         last_lane[0] = k
-        with torch.cuda.stream(stream):
+        with stream_ctx(stream):
             cA, cB = make_crops(0)
             e.preprocess(cA, e.input_buffer_ptr(0))
             e.preprocess(cB, e.input_buffer_ptr(1))
@@ -292,33 +315,34 @@ def main():
         """Untimed: `steps` pipelined steps queued back to back, the outputs of EVERY step kept (cloned on its own
         stream) and compared with the single-stream results `want` = (trans, rot, pose).  Returns the number of
         steps whose outputs are not bit-identical."""
-        torch.cuda.synchronize()
+        sync()
         kept = []
         for _ in range(steps):
             step_pipelined()
             k = last_lane[0]
-            with torch.cuda.stream(pe.streams[k]):
+            with stream_ctx(pe.streams[k]):
                 kept.append(tuple(x.clone() for x in lane_out[k]))
-        torch.cuda.synchronize()
+        sync()
         return sum(0 if all(torch.equal(a, b) for a, b in zip(o, want)) else 1 for o in kept)
 
     def timed_loop_pipelined(steps):
-        torch.cuda.synchronize()
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             step_pipelined()
         for st_ in pe.streams:                                 # the collective (and the clock) wait for every lane
-            torch.cuda.current_stream().wait_stream(st_)
+            if not DRY:
+                torch.cuda.current_stream().wait_stream(st_)
         if use_dist:
             dist_mod.gather_poses(lane_out[last_lane[0]][2])   # C2, once per timed region as in the single-stream loop
-        torch.cuda.synchronize()
+        sync()
         local_dt[0] = time.perf_counter() - t0
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         dtp = time.perf_counter() - t0
         if use_dist:
             t_ = torch.tensor([dtp], dtype=torch.float64, device=dev)
@@ -335,6 +359,19 @@ def main():
         allr = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allr, t)
         per_rank = [float(x.item()) for x in allr]
+
+    dry_checks = None
+    if DRY and use_dist:
+        # the gathered poses carry every rank's marker (DryEngine.infer writes rank + 1 into element 15), the blob every rank
+        # holds is byte-identical to rank 0's (checksum), and its size is what the library packs
+        allp = dist_mod.gather_poses(poseB)
+        marks = [float(allp[r * nb, 15]) for r in range(world)]
+        csum = torch.tensor([int(blob.to(torch.int64).sum())])
+        sums = [torch.zeros_like(csum) for _ in range(world)]
+        dist.all_gather(sums, csum)
+        dry_checks = {"gathered_rank_markers": marks, "gather_ok": marks == [float(r + 1) for r in range(world)],
+                      "blob_bytes": int(blob.numel()), "blob_identical_on_all_ranks": len({int(x) for x in sums}) == 1}
+        assert dry_checks["gather_ok"] and dry_checks["blob_identical_on_all_ranks"], dry_checks
 
     # ---- roofline of the dominant kernel family, from the HIP events of the timed region ----
     conv_ms, tot_ms, nconv = [], [], 0
@@ -378,7 +415,7 @@ def main():
                           "tflops": round(fl / (ms * 1e-3) / 1e12, 1), "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
     dominant = max(per_layer, key=lambda d_: d_["ms"]) if per_layer else None
     eng.profile_enable(0)
-    torch.cuda.synchronize()
+    sync()
     pose_main = poseB.clone()
     trans_main, rot_main = trans.clone(), rot.clone()
 
@@ -501,6 +538,7 @@ def main():
                                       "alternate over %d HIP stream(s)" %
                                       (world, "every step (overlapped)" if args.gather_every_step else "once per timed region", lanes)},
             "rccl_ranks": dist.get_world_size() if use_dist else 1,
+            "backend": dist.get_backend() if use_dist else None,
             "per_rank_pairs_per_s": pipelined["per_rank_pairs_per_s"] if pipelined else [round(v, 1) for v in per_rank],
             "tflops_total": round(value * FLOP_PER_PAIR / 1e12, 2),
             "roofline": {"bound": "mfma",
@@ -531,6 +569,10 @@ def main():
                                                            if pipelined else None)}},
             "layers_ms": {n: round(ms, 4) for n, ms in layers},
         }
+        if DRY:
+            out["dry_run"] = ("gloo on CPU, every kernel stubbed out: `value`, `roofline` and `layers_ms` are NOT measurements; this "
+                              "line only shows that the N-rank launch, broadcast, gather and reporting path runs")
+            out["dry_run_checks"] = dry_checks
         if pipelined:
             out["pipelined"] = pipelined
         if short is not None:
@@ -560,6 +602,82 @@ def main():
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+
+
+class DryEngine:
+    """--dry-run-gloo only: stands where se3.Engine stands.  The weight blob is the REAL one (the library's host packer through a
+    device -1 context); every device call is a no-op, `infer` writes poseA with this rank's marker into poseB."""
+
+    def __init__(self, se3, rank, nb):
+        self.host = se3.Engine(device=-1, max_batch=1)
+        self.rank, self.max_batch, self.device, self.blob = rank, nb, -1, None
+        self._slots = 0
+
+    def pack_state_dict(self, sd):
+        return self.host.pack_state_dict(sd)
+
+    def packed_bytes(self):
+        return self.host.packed_bytes()
+
+    def bind_blob(self, blob):
+        import numpy as np
+        assert blob.numel() == self.packed_bytes() and bytes(np.asarray(blob[:4])) == b"T3ES", "bad blob header"
+        self.blob = blob
+
+    def input_buffer_ptr(self, which):
+        return 0
+
+    def preprocess(self, crops, out):
+        pass
+
+    def infer(self, A, B, n, layout, trans, rot, poseA, poseB):
+        poseB.copy_(poseA)
+        poseB[:, 15] = self.rank + 1
+        trans.zero_(); rot.zero_()
+
+    def profile_enable(self, slots=1):
+        self._slots = slots
+
+    def profile_read(self, slot=0):
+        return 1.0, 10, 1.2
+
+    def profile_launches(self, slot=0):
+        return [("stem7x7_mfma", 0.2), ("convAB1 s2", 0.5), ("trans|rot conv1 s2", 0.5)]
+
+    def get_winograd(self):
+        return 8, 4
+
+    def overflow(self):
+        return False
+
+    def __getattr__(self, name):
+        if name.startswith("set_"):
+            return lambda *a, **k: None
+        raise AttributeError(name)
+
+
+class DryPipelinedEngine:
+    def __init__(self, se3, rank, nb, lanes):
+        self.engines = [DryEngine(se3, rank, nb) for _ in range(lanes)]
+        self.streams = [None] * lanes
+        self._i = 0
+
+    def load_state_dict(self, sd):
+        self.bind_blob(self.engines[0].pack_state_dict(sd))
+
+    def bind_blob(self, blob):
+        for e in self.engines:
+            e.bind_blob(blob)
+
+    def next_lane(self):
+        k = self._i % len(self.engines)
+        self._i += 1
+        return self.engines[k], self.streams[k]
+
+    def __getattr__(self, name):
+        if name.startswith("set_"):
+            return lambda *a, **k: None
+        raise AttributeError(name)
 
 
 def compare_with_oracle(np, orc, trans, rot, pose):

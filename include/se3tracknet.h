@@ -8,8 +8,13 @@
  * Conventions
  *   - plain C types only; device pointers are caller-owned (e.g. torch tensors' data_ptr());
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
- *   - every se3tn_* compute call is stream-ordered and asynchronous: no hidden hipMalloc,
- *     no hipDeviceSynchronize, no host<->device copy of results => hipGraph-capturable;
+ *   - every se3tn_* compute call (preprocess, crop_raw, infer, render, render_frame, fill_depth) is stream-ordered and
+ *     asynchronous: no hipMalloc, no hipDeviceSynchronize, no host<->device copy of results => hipGraph-capturable.
+ *     All device memory is allocated by the init-time calls: se3tn_create (activations, 176x176 z-buffer),
+ *     se3tn_upload_weights / se3tn_bind_weights / se3tn_set_winograd (Winograd planes), se3tn_set_precision (f16x3 split
+ *     panels), se3tn_mesh_create / _set_texture, and se3tn_reserve (full-frame z-buffer + fill_depth scratch).  The two
+ *     full-frame calls grow their scratch on a first un-reserved call with a larger frame (draining the device first);
+ *     inside a stream capture they refuse with SE3TN_E_STATE instead -- call se3tn_reserve at start-up;
  *   - return value: 0 = ok, >0 = a hipError_t, <0 = SE3TN_E_*; se3tn_last_error() has the text;
  *   - one context per (process, device); a context is thread-compatible, not thread-safe.
  */
@@ -48,6 +53,11 @@ const char* se3tn_last_error(void);
 int se3tn_create(int device, int max_batch, se3tn_ctx** out);
 void se3tn_destroy(se3tn_ctx* ctx);
 int se3tn_max_batch(const se3tn_ctx* ctx);
+/* Start-up reservation of everything the stream-ordered calls would otherwise have to allocate on first use: the
+ * z-buffer of se3tn_render_frame and the scratch images of se3tn_fill_depth for camera frames of up to H x W pixels
+ * (Tracker.__init__ knows them from dataset_info['camera'], predict.py:147-148), and, if weights are bound, the Winograd
+ * planes / f16x3 split panels of the modes currently selected.  Synchronises the device when it has to re-allocate. */
+int se3tn_reserve(se3tn_ctx* ctx, int H, int W);
 
 /* ---- weights: `model.load_state_dict(checkpoint['state_dict'])` (predict.py:151-156) ------ */
 /* Hand over one float32 entry of Se3TrackNet.state_dict() (host memory, contiguous, the key and
@@ -63,7 +73,8 @@ const void* se3tn_packed_host(const se3tn_ctx* ctx); /* host pointer, valid afte
 /* Single-GPU: library-owned device copy of the packed blob. */
 int se3tn_upload_weights(se3tn_ctx* ctx, void* stream);
 /* Multi-GPU: use a caller-owned device blob in packed format (rank 0 packs, RCCL broadcasts
- * the bytes, every rank binds its copy).  The blob must outlive the context. */
+ * the bytes, every rank binds its copy).  The blob must outlive the context.  The blob holds the BN-folded float32
+ * panels only (54 MB); the Winograd planes and the f16x3 split panels are derived from it on each rank's device. */
 int se3tn_bind_weights(se3tn_ctx* ctx, const void* device_blob, size_t bytes);
 
 /* ---- per-dataset constants --------------------------------------------------------------- */
@@ -78,8 +89,15 @@ int se3tn_set_normalization(se3tn_ctx* ctx, const double mean[8], const double s
  *                    se3tn_overflow reports (and clears) a violation -- rerun in SE3TN_PREC_F32 then. */
 #define SE3TN_PREC_F32 0
 #define SE3TN_PREC_F16X3 1
+/* Init-time call: the first selection of SE3TN_PREC_F16X3 (and a later change of weights while it is selected) derives the
+ * split-f16 panels + per-cout power-of-two scales from the bound blob on the device (54 MB, allocated once). */
 int se3tn_set_precision(se3tn_ctx* ctx, int mode);
 int se3tn_overflow(se3tn_ctx* ctx, int* flag); /* synchronises */
+/* Test hooks for that derivation: the device copy (NULL until derived) and its size, and the host statement of the same
+ * arithmetic applied to a packed blob in host memory (se3tn_packed_host) -- the two must agree bit for bit. */
+size_t se3tn_split_weights_bytes(const se3tn_ctx* ctx);
+const void* se3tn_split_weights_device(const se3tn_ctx* ctx);
+int se3tn_split_weights_host(const void* packed_blob_host, size_t blob_bytes, void* out_split, size_t out_bytes);
 /* Algorithm of the stride-1 256/512-channel convolutions (AB2.*, trans|rot conv2.*) in
  * SE3TN_PREC_F32: batches of n >= min_batch pairs run them as Winograd F(tile x tile, 3x3), tile = 2 | 4
  * (0 keeps the current tile) -- float32 MFMA GEMMs on (tile+2)^2 transformed planes, 2.25x / 4x fewer
@@ -164,7 +182,7 @@ int se3tn_render(se3tn_ctx* ctx, se3tn_mesh* mesh, const double ob_in_cam[16], c
  * (NULL: 1,1,1); host pointers, copied; the mip pyramid is built here.  se3tn_render_frame writes device
  * rgb uint8 [H,W,3] and depth uint16 [H,W] millimetres ((depth * 1000).astype(uint16), predict.py:211); feed
  * them to se3tn_preprocess / se3tn_crop_raw with the plain compute_bbox window exactly like a camera frame
- * (predict.py:209-213).  The first call for a larger frame allocates its z-buffer. */
+ * (predict.py:209-213).  Z-buffer: se3tn_reserve(ctx, H, W) at start-up (else grown on the first call, see Conventions). */
 int se3tn_mesh_set_texture(se3tn_mesh* mesh, const float* uv, const uint8_t* rgb, int tw, int th, const float kd[3]);
 int se3tn_render_frame(se3tn_ctx* ctx, se3tn_mesh* mesh, const double ob_in_cam[16], const double K[9], int W, int H,
                        uint8_t* rgb, uint16_t* depth, void* stream);
@@ -174,8 +192,8 @@ int se3tn_render_frame(se3tn_ctx* ctx, se3tn_mesh* mesh, const double ob_in_cam[
  *     depth = fill_depth(depth_mm / 1e3, max_depth, extrapolate, blur_type);  out_mm = (depth * 1000).astype(uint16)
  * depth_mm: device uint16 [H,W] millimetres; out_mm: device uint16 [H,W] and / or out_m: device float32 [H,W] metres
  * (either may be NULL).  blur: the reference's blur_type ('bilateral' is its default; anything else but 'gaussian'
- * skips the blur).  The first call for a frame size larger than any before allocates the scratch images (the one
- * exception to "no hidden hipMalloc"; call it once at start-up). */
+ * skips the blur).  Scratch images: se3tn_reserve(ctx, H, W) at start-up (else grown on the first call, see Conventions).
+ * A context's scratch is shared by its calls: use one stream per context for se3tn_fill_depth / se3tn_render*. */
 #define SE3TN_BLUR_NONE 0
 #define SE3TN_BLUR_BILATERAL 1
 #define SE3TN_BLUR_GAUSSIAN 2

@@ -41,6 +41,10 @@ _SIGS = {
     "se3tn_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "se3tn_destroy": (None, [C.c_void_p]),
     "se3tn_max_batch": (C.c_int, [C.c_void_p]),
+    "se3tn_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "se3tn_split_weights_bytes": (C.c_size_t, [C.c_void_p]),
+    "se3tn_split_weights_device": (C.c_void_p, [C.c_void_p]),
+    "se3tn_split_weights_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "se3tn_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "se3tn_pack_weights": (C.c_int, [C.c_void_p]),
     "se3tn_packed_bytes": (C.c_size_t, [C.c_void_p]),

@@ -72,6 +72,9 @@ struct se3tn_ctx {
   float* wino_u[4] = {nullptr, nullptr, nullptr, nullptr};  // U = G g G^T of LAB2_1, LAB2_2, LH2_1, LH2_2
   float *wino_v = nullptr, *wino_m = nullptr;   // [g][16][T][C] input tiles / per-frequency products
   const float* wino_blob = nullptr;             // the blob wino_u was derived from
+  SplitLayout SL;                               // f16x3 mode: split panels in split_w (derived from the blob, not part of it)
+  float* split_w = nullptr;
+  const float* split_blob = nullptr;            // the blob split_w was derived from
   int prec = SE3TN_PREC_F32;                    // se3tn_set_precision
   int in_split[2] = {0, 0};                     // pixel format currently held by inA / inB
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
@@ -148,9 +151,46 @@ static int wino_prepare(se3tn_ctx* c, hipStream_t st) {
   return SE3TN_OK;
 }
 
+// f16x3 mode: the split-f16 panels + per-cout scales, derived on the device from the bound float32 blob (init time: called
+// from se3tn_set_precision / se3tn_upload_weights / se3tn_bind_weights, never from a stream-ordered compute call)
+static int split_prepare(se3tn_ctx* c, hipStream_t st) {
+  if (c->device < 0 || c->prec != SE3TN_PREC_F16X3 || !c->blob || c->split_blob == c->blob) return SE3TN_OK;
+  if (!c->split_w) HIPCHK(hipMalloc((void**)&c->split_w, c->SL.total * sizeof(float)));
+  HIPCHK(launch_split_weights(c->blob, c->L, c->split_w, c->SL, st));
+  HIPCHK(hipStreamSynchronize(st));  // init-time
+  c->split_blob = c->blob;
+  return SE3TN_OK;
+}
+
+// scratch of se3tn_fill_depth (3 float images + min/max + table) and the rasteriser's z-buffer: grown here, at start-up
+// (se3tn_reserve) or on the first call with a larger frame.  Growing frees the old buffer, so the whole DEVICE is drained
+// first: another stream of this context may still be reading it.
+static int reserve_fill_depth(se3tn_ctx* c, size_t px) {
+  if (px <= c->fd_pixels) return SE3TN_OK;
+  HIPCHK(hipDeviceSynchronize());
+  if (c->fd_buf) HIPCHK(hipFree(c->fd_buf));
+  c->fd_buf = nullptr; c->fd_pixels = 0;
+  HIPCHK(hipMalloc((void**)&c->fd_buf, (3 * px + 2 + 4098 + 2) * sizeof(float)));
+  c->fd_pixels = px;
+  return SE3TN_OK;
+}
+static int reserve_zbuf(se3tn_ctx* c, size_t px) {
+  if (px <= c->zbuf_px) return SE3TN_OK;
+  HIPCHK(hipDeviceSynchronize());
+  if (c->zbuf) HIPCHK(hipFree(c->zbuf));
+  c->zbuf = nullptr; c->zbuf_px = 0;
+  HIPCHK(hipMalloc((void**)&c->zbuf, sizeof(unsigned long long) * px));
+  c->zbuf_px = px;
+  return SE3TN_OK;
+}
+static bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
 extern "C" {
 
-const char* se3tn_version(void) { return "se3tracknet-gfx950 0.4.0 (blob v6)"; }
+const char* se3tn_version(void) { return "se3tracknet-gfx950 0.5.0 (blob v7)"; }
 const char* se3tn_last_error(void) { return g_err.c_str(); }
 
 int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
@@ -159,6 +199,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
   c->device = device;
   c->max_batch = max_batch;
   c->L = blob_layout();
+  c->SL = split_layout();
   for (int i = 0; i < 8; ++i) { c->mean[i] = 0.0; c->stdv[i] = 1.0; }
   if (device >= 0) {
     hipDeviceProp_t prop;
@@ -210,7 +251,7 @@ void se3tn_destroy(se3tn_ctx* c) {
   if (!c) return;
   if (c->device >= 0) {
     float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
-                     c->head_t, c->head_f, c->logits, c->fcpart, c->part, c->blob_owned, c->wino_v, c->wino_m,
+                     c->head_t, c->head_f, c->logits, c->fcpart, c->part, c->blob_owned, c->split_w, c->wino_v, c->wino_m,
                      c->wino_u[0], c->wino_u[1], c->wino_u[2], c->wino_u[3]};
     for (float* b : bufs)
       if (b) (void)hipFree(b);
@@ -266,6 +307,8 @@ int se3tn_upload_weights(se3tn_ctx* c, void* stream) {
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));  // init-time only: the host vector may go away
   c->blob = c->blob_owned;
   c->wino_blob = nullptr;  // same address, new contents
+  c->split_blob = nullptr;
+  if (int rc = split_prepare(c, (hipStream_t)stream)) return rc;
   return wino_prepare(c, (hipStream_t)stream);
 }
 
@@ -278,6 +321,8 @@ int se3tn_bind_weights(se3tn_ctx* c, const void* device_blob, size_t bytes) {
     return fail(SE3TN_E_SHAPE, "se3tn_bind_weights: bad blob header");
   c->blob = (const float*)device_blob;
   c->wino_blob = nullptr;
+  c->split_blob = nullptr;
+  if (int rc = split_prepare(c, nullptr)) return rc;
   return wino_prepare(c, nullptr);
 }
 
@@ -308,6 +353,27 @@ int se3tn_set_normalization(se3tn_ctx* c, const double mean[8], const double std
 int se3tn_set_precision(se3tn_ctx* c, int mode) {
   if (!c || (mode != SE3TN_PREC_F32 && mode != SE3TN_PREC_F16X3)) return fail(SE3TN_E_ARG, "se3tn_set_precision: bad mode");
   c->prec = mode;
+  // first selection of f16x3 (or new weights since): derive the split panels from the bound blob -- here, not in se3tn_infer
+  return split_prepare(c, nullptr);
+}
+
+int se3tn_reserve(se3tn_ctx* c, int H, int W) {
+  if (!c || c->device < 0 || H < 1 || W < 1) return fail(SE3TN_E_ARG, "se3tn_reserve: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (int rc = reserve_fill_depth(c, (size_t)H * W)) return rc;
+  if (int rc = reserve_zbuf(c, (size_t)H * W)) return rc;
+  if (int rc = wino_prepare(c, nullptr)) return rc;
+  return split_prepare(c, nullptr);
+}
+
+size_t se3tn_split_weights_bytes(const se3tn_ctx* c) { return c ? c->SL.total * sizeof(float) : 0; }
+const void* se3tn_split_weights_device(const se3tn_ctx* c) { return (c && c->split_blob) ? c->split_w : nullptr; }
+int se3tn_split_weights_host(const void* packed_blob_host, size_t blob_bytes, void* out_split, size_t out_bytes) {
+  const BlobLayout L = blob_layout();
+  const SplitLayout S = split_layout();
+  if (!packed_blob_host || !out_split || blob_bytes != L.total * sizeof(float) || out_bytes != S.total * sizeof(float))
+    return fail(SE3TN_E_ARG, "se3tn_split_weights_host: bad argument");
+  split_blob_host((const float*)packed_blob_host, (float*)out_split);
   return SE3TN_OK;
 }
 
@@ -471,8 +537,12 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
   if (c->in_split[0] != want_split || c->in_split[1] != want_split)
     return fail(SE3TN_E_STATE, "se3tn_infer: the input buffers were filled under a different precision mode "
                                "(call se3tn_set_precision before se3tn_preprocess)");
+  if (want_split && c->split_blob != c->blob)
+    return fail(SE3TN_E_STATE, "se3tn_infer: f16x3 split panels not derived (se3tn_set_precision after the weights are bound)");
+  const float* WS = c->split_w;
+  const SplitLayout& SL = c->SL;
   if (want_split)
-    HIPCHK(launch_stem(A, B, W + L.stem_ws, W + L.stem_b, W + L.stem_sc, c->stem, n, st));
+    HIPCHK(launch_stem(A, B, WS + SL.stem_ws, W + L.stem_b, WS + SL.stem_sc, c->stem, n, st));
   else
     HIPCHK(launch_stem(A, B, W + L.stem_w, W + L.stem_b, nullptr, c->stem, n, st));
   HIPCHK((hipError_t)prof_mark(c, st, "stem7x7_mfma", false));
@@ -505,8 +575,8 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
     if (fast) {
       a.fast = 1;
       a.overflow = c->overflow;
-      a.w = W + L.conv_ws[id];
-      a.wscale = W + L.conv_sc[id];
+      a.w = WS + SL.conv_ws[id];
+      a.wscale = WS + SL.conv_sc[id];
     } a.res = res; a.out = out; a.part = c->part; a.part_bytes = c->part_bytes;
     a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
     a.H = hin; a.W = hin; a.Ho = (hin - 1) / stride + 1; a.Wo = a.Ho;
@@ -623,6 +693,7 @@ int se3tn_mesh_create(se3tn_ctx* c, const float* verts, const float* normals, co
 int se3tn_mesh_set_texture(se3tn_mesh* m, const float* uv, const uint8_t* rgb, int tw, int th, const float kd[3]) {
   if (!m || (rgb && (!uv || tw < 1 || th < 1))) return fail(SE3TN_E_ARG, "se3tn_mesh_set_texture: bad argument");
   if (kd) { m->kd[0] = kd[0]; m->kd[1] = kd[1]; m->kd[2] = kd[2]; }
+  if (m->uv || m->tex) (void)hipDeviceSynchronize();   // a render may still be reading the old material
   if (m->uv) { (void)hipFree(m->uv); m->uv = nullptr; }
   if (m->tex) { (void)hipFree(m->tex); m->tex = nullptr; }
   m->tlevels = 0;
@@ -650,10 +721,19 @@ int se3tn_mesh_set_texture(se3tn_mesh* m, const float* uv, const uint8_t* rgb, i
     m->tex_off[levels] = (unsigned)noff;
     off = noff; w = nw; h = nh; ++levels;
   }
-  HIPCHK(hipMalloc((void**)&m->tex, pyr.size()));
-  HIPCHK(hipMemcpy(m->tex, pyr.data(), pyr.size(), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc((void**)&m->uv, sizeof(float) * 2 * m->V));
-  HIPCHK(hipMemcpy(m->uv, uv, sizeof(float) * 2 * m->V, hipMemcpyHostToDevice));
+  // both buffers exist and are filled before either is published: the resolve kernel reads uv whenever tex is set
+  uint8_t* d_tex = nullptr;
+  float* d_uv = nullptr;
+  hipError_t e = hipMalloc((void**)&d_tex, pyr.size());
+  if (e == hipSuccess) e = hipMemcpy(d_tex, pyr.data(), pyr.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_uv, sizeof(float) * 2 * m->V);
+  if (e == hipSuccess) e = hipMemcpy(d_uv, uv, sizeof(float) * 2 * m->V, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (d_tex) (void)hipFree(d_tex);
+    if (d_uv) (void)hipFree(d_uv);
+    return hipfail(e, "se3tn_mesh_set_texture");
+  }
+  m->tex = d_tex; m->uv = d_uv;
   m->tw = tw; m->th = th; m->tlevels = levels;
   return SE3TN_OK;
 }
@@ -694,12 +774,10 @@ int se3tn_fill_depth(se3tn_ctx* c, const uint16_t* depth_mm, int H, int W, doubl
   if (!c || c->device < 0 || !depth_mm || H < 1 || W < 1 || (!out_mm && !out_m) || blur < 0 || blur > 2)
     return fail(SE3TN_E_ARG, "se3tn_fill_depth: bad argument");
   const size_t px = (size_t)H * W;
-  if (px > c->fd_pixels) {   // start-up (or a larger camera): scratch images
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    if (c->fd_buf) HIPCHK(hipFree(c->fd_buf));
-    c->fd_buf = nullptr; c->fd_pixels = 0;
-    HIPCHK(hipMalloc((void**)&c->fd_buf, (3 * px + 2 + 4098 + 2) * sizeof(float)));
-    c->fd_pixels = px;
+  if (px > c->fd_pixels) {   // not reserved (se3tn_reserve): grow now -- impossible inside a stream capture
+    if (stream_is_capturing((hipStream_t)stream))
+      return fail(SE3TN_E_STATE, "se3tn_fill_depth: scratch too small for this frame inside a stream capture: call se3tn_reserve(ctx, H, W) first");
+    if (int rc = reserve_fill_depth(c, px)) return rc;
   }
   FillDepthArgs a{};
   a.depth_mm = depth_mm; a.H = H; a.W = W; a.max_depth = max_depth_m; a.extrapolate = extrapolate; a.blur = blur;
@@ -717,12 +795,10 @@ int se3tn_render_frame(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], 
   if (!c || c->device < 0 || !m || !ob_in_cam || !K || !rgb || !depth || W < 1 || H < 1)
     return fail(SE3TN_E_ARG, "se3tn_render_frame: bad argument");
   const size_t px = (size_t)W * H;
-  if (px > c->zbuf_px) {   // first full-frame render (start-up): a z-buffer of the camera's size
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    (void)hipFree(c->zbuf);
-    c->zbuf = nullptr; c->zbuf_px = 0;
-    HIPCHK(hipMalloc((void**)&c->zbuf, sizeof(unsigned long long) * px));
-    c->zbuf_px = px;
+  if (px > c->zbuf_px) {   // not reserved (se3tn_reserve): grow now -- impossible inside a stream capture
+    if (stream_is_capturing((hipStream_t)stream))
+      return fail(SE3TN_E_STATE, "se3tn_render_frame: z-buffer too small for this frame inside a stream capture: call se3tn_reserve(ctx, H, W) first");
+    if (int rc = reserve_zbuf(c, px)) return rc;
   }
   RasterArgs a{};
   a.verts = m->verts; a.normals = m->normals; a.colors = m->colors; a.faces = m->faces; a.vwin = m->vwin;

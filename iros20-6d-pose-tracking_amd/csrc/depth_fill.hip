@@ -205,8 +205,12 @@ __global__ __launch_bounds__(256) void fd_finish_kernel(const float* __restrict_
   if (d > 0.1f) d = max_depth - d;
   if (out_m) out_m[i] = d;
   if (out_mm) {
+    // (depth * 1000).astype(np.uint16) as NumPy evaluates it on x86-64: truncate to int32, keep the low 16 bits.  A region
+    // beyond max_depth stays NEGATIVE through dilate / close / fill / median (inverted depth max_depth - d < 0 is "empty"
+    // and only its rim is filled), so e.g. -0.5 m -> -500 -> 65036, not 0.  Either value is "invalid" for OffsetDepth
+    // (<= 100 or >= 2000 -> 2000, data_augmentation.py:136), but the uint16 frame is the reference's bit for bit.
     const float mm = d * 1000.f;
-    out_mm[i] = (uint16_t)(int)fminf(fmaxf(mm, 0.f), 65535.f);   // truncation, as astype
+    out_mm[i] = (uint16_t)(unsigned)(int)mm;
   }
 }
 

@@ -228,4 +228,61 @@ hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h,
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// f16x3 mode: split panels of one packed weight matrix, derived on the device (init time; the blob carries float32 only).
+// One workgroup per cout row: max |w| over the row -> exact power-of-two scale (split_exponent) -> hi | lo f16 parts.
+// rows x [cout][32] layout of the 3x3 panels (row_words = 32, rows = chunks x 9 taps, hi at +0, lo at +32 halves), or the
+// stem's [64][204] (one "row" of 200 used words per cout, 16-byte entries 4 hi | 4 lo).  weights.cpp: split_blob_host is the
+// host statement of the same arithmetic (checked bit for bit in tests/test_gpu_parity.py).
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, _Float16* __restrict__ ws,
+                                                             float* __restrict__ sc, int rows, int cout, int stem) {
+  __shared__ float red[256];
+  const int o = blockIdx.x, t = threadIdx.x;
+  const int per_row = stem ? 200 : 32;
+  const size_t row_stride = stem ? 0 : (size_t)cout * 32;           // words between consecutive rows of one cout
+  const size_t base = stem ? (size_t)o * 204 : (size_t)o * 32;
+  float mx = 0.f;
+  for (int i = t; i < rows * per_row; i += 256) {
+    const int r = i / per_row, ci = i - r * per_row;
+    mx = fmaxf(mx, fabsf(w[base + r * row_stride + ci]));
+  }
+  red[t] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) red[t] = fmaxf(red[t], red[t + s]);
+    __syncthreads();
+  }
+  const int k = split_exponent(red[0]);
+  const float scl = ldexpf(1.0f, k);
+  if (t == 0) sc[o] = ldexpf(1.0f, -k);
+  for (int i = t; i < rows * per_row; i += 256) {
+    const int r = i / per_row, ci = i - r * per_row;
+    const size_t word = base + r * row_stride + ci;
+    const float v = w[word] * scl;                                   // exact (power of two)
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    // 3x3 panels: a 32-word row = 32 hi | 32 lo halves;   stem: a 4-word entry = 4 hi | 4 lo halves
+    const size_t h = stem ? ((size_t)o * 204 + (ci & ~3)) * 2 + (ci & 3) : (base + r * row_stride) * 2 + ci;
+    ws[h] = hi;
+    ws[h + (stem ? 4 : 32)] = lo;
+  }
+}
+
+hipError_t launch_split_weights(const float* blob, const BlobLayout& L, float* split, const SplitLayout& S, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(split, 0, S.total * sizeof(float), st);
+  if (e != hipSuccess) return e;
+  const Conv3* spec = conv_specs();
+  for (int id = 0; id < NUM_CONV3; ++id)
+    for (int g = 0; g < spec[id].groups; ++g) {
+      const size_t gw = conv3_words(spec[id].cin, spec[id].cout) * g;
+      hipLaunchKernelGGL(split_weights_kernel, dim3(spec[id].cout), dim3(256), 0, st, blob + L.conv_w[id] + gw,
+                         reinterpret_cast<_Float16*>(split + S.conv_ws[id] + gw), split + S.conv_sc[id] + (size_t)spec[id].cout * g,
+                         spec[id].cin / 32 * 9, spec[id].cout, 0);
+    }
+  for (int br = 0; br < 2; ++br)
+    hipLaunchKernelGGL(split_weights_kernel, dim3(64), dim3(256), 0, st, blob + L.stem_w + (size_t)br * 64 * 204,
+                       reinterpret_cast<_Float16*>(split + S.stem_ws + (size_t)br * 64 * 204), split + S.stem_sc + br * 64, 1, 64, 1);
+  return hipGetLastError();
+}
+
 }  // namespace se3tn

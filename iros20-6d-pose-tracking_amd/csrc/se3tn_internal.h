@@ -46,14 +46,8 @@ struct BlobLayout {
   // offsets in float32 words
   size_t stem_w;   // [2 branches][64][204]
   size_t stem_b;   // [2][64]
-  size_t stem_ws;  // f16x3: [2][64][204] words, each 16-byte (pair, half) entry = 4 f16 hi | 4 f16 lo
-  size_t stem_sc;  // f16x3: [2][64] per-cout 2^-k
   size_t conv_w[NUM_CONV3];
   size_t conv_b[NUM_CONV3];
-  // f16x3 mode: the same panels as "split rows"
-  // (32 x f16 hi | 32 x f16 lo of w * 2^k per cout) and the per-cout 2^-k
-  size_t conv_ws[NUM_CONV3];
-  size_t conv_sc[NUM_CONV3];
   size_t fc_w;     // [2 heads][3][512]
   size_t fc_b;     // [2][4] (3 used)
   size_t total;    // words, incl. the 64-word header
@@ -61,7 +55,18 @@ struct BlobLayout {
 
 constexpr int HEADER_WORDS = 64;
 constexpr uint32_t BLOB_MAGIC = 0x53453354u;  // 'SE3T'
-constexpr uint32_t BLOB_VERSION = 6;
+constexpr uint32_t BLOB_VERSION = 7;  // 7: float32 panels only (54 MB); the f16x3 split panels are derived on the device
+
+// f16x3 mode: the same panels as "split rows" (32 x f16 hi | 32 x f16 lo of w * 2^k per cout) and the per-cout 2^-k.
+// NOT part of the blob (since v7): a context-owned device buffer derived from the bound blob by launch_split_weights when
+// SE3TN_PREC_F16X3 is first selected -- like the Winograd planes, so the RCCL broadcast carries the float32 panels only.
+struct SplitLayout {
+  size_t stem_ws;  // [2][64][204] words, each 16-byte (pair, half) entry = 4 f16 hi | 4 f16 lo
+  size_t stem_sc;  // [2][64] per-cout 2^-k
+  size_t conv_ws[NUM_CONV3];
+  size_t conv_sc[NUM_CONV3];
+  size_t total;    // words
+};
 
 inline const Conv3* conv_specs() {
   static const Conv3 s[NUM_CONV3] = {
@@ -75,22 +80,43 @@ inline BlobLayout blob_layout() {
   size_t o = HEADER_WORDS;
   L.stem_w = o; o += (size_t)2 * 64 * 204;
   L.stem_b = o; o += 2 * 64;
-  L.stem_ws = o; o += (size_t)2 * 64 * 204;
-  L.stem_sc = o; o += 2 * 64;
   const Conv3* s = conv_specs();
   for (int i = 0; i < NUM_CONV3; ++i) {
     L.conv_w[i] = o; o += conv3_words(s[i].cin, s[i].cout) * s[i].groups;
     L.conv_b[i] = o; o += (size_t)s[i].cout * s[i].groups;
-  }
-  for (int i = 0; i < NUM_CONV3; ++i) {
-    L.conv_ws[i] = o; o += conv3_words(s[i].cin, s[i].cout) * s[i].groups;
-    L.conv_sc[i] = o; o += (size_t)s[i].cout * s[i].groups;
   }
   L.fc_w = o; o += 2 * 3 * 512;
   L.fc_b = o; o += 2 * 4;
   o = (o + 63) & ~(size_t)63;
   L.total = o;
   return L;
+}
+
+inline SplitLayout split_layout() {
+  SplitLayout L{};
+  size_t o = 0;
+  L.stem_ws = o; o += (size_t)2 * 64 * 204;
+  L.stem_sc = o; o += 2 * 64;
+  const Conv3* s = conv_specs();
+  for (int i = 0; i < NUM_CONV3; ++i) {
+    L.conv_ws[i] = o; o += conv3_words(s[i].cin, s[i].cout) * s[i].groups;
+    L.conv_sc[i] = o; o += (size_t)s[i].cout * s[i].groups;
+  }
+  o = (o + 63) & ~(size_t)63;
+  L.total = o;
+  return L;
+}
+
+// Exponent k of the exact per-cout power-of-two weight scaling of the f16x3 mode: the largest |w| of a cout row lands in
+// [2^10, 2^11) (k = floor(10 - log2(mx)), evaluated on the float's own exponent so that host and device agree bit for bit).
+__host__ __device__ inline int split_exponent(float mx) {
+  if (!(mx > 0.f)) return 0;
+  int e;
+  const float m = frexpf(mx, &e);  // mx = m 2^e, m in [0.5, 1)
+  int k = (m == 0.5f) ? 11 - e : 10 - e;
+  if (k > 40) k = 40;
+  if (k < -20) k = -20;
+  return k;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -162,7 +188,7 @@ struct TailArgs {
 };
 
 struct CropArgs {  // one launch handles up to MAX crops
-  static constexpr int MAX = 64;  // 64 x 48 B + constants = 3.3 KB of kernel arguments (< 4 KB)
+  static constexpr int MAX = 64;  // 64 x 56 B + constants = 3.75 KB of kernel arguments (limit 4 KB, asserted below)
   se3tn_crop c[MAX];
   double mean[8], stdv[8];
   float* out;   // plain [n,176,176,4], or (padded != 0) the interior of [n,182,182,4]
@@ -171,6 +197,8 @@ struct CropArgs {  // one launch handles up to MAX crops
   int split;    // f16x3 mode: a pixel is stored as 4 x f16 hi | 4 x f16 lo (same 16 bytes)
   int* overflow;
 };
+
+static_assert(sizeof(CropArgs) <= 4096, "CropArgs travels as kernel arguments: HIP's limit is 4 KB");
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies per DEVICE: a launcher remembers which device
 // ordinals it has already raised the limit on (several contexts on different GPUs in one process).
@@ -185,6 +213,8 @@ struct PerDeviceOnce {
 };
 
 // launchers (defined in the .hip files)
+// f16x3 split panels + per-cout scales of every conv / both stems from the bound float32 blob (kernels_misc.hip)
+hipError_t launch_split_weights(const float* blob, const BlobLayout& L, float* split, const SplitLayout& S, hipStream_t st);
 // NCHW [n,4,176,176] (nchw != 0) or plain NHWC [n,176,176,4] -> interior of the padded [n,182,182,4]
 hipError_t launch_to_padded_input(const float* in, float* out, int n, int nchw, int split, int* overflow,
                                   hipStream_t st);

@@ -119,34 +119,6 @@ float f16_bits_to_f32(uint16_t h) {
   return f;
 }
 
-// OIHW 3x3 -> split rows [chunk][tap][cout_total][32 f16 hi | 32 f16 lo] of w * 2^k(cout), k chosen
-// so that the largest |w| of the cout row sits near 2^10; inv_scale[o] = 2^-k
-void pack3_split(const Folded& f, float* dst, float* inv_scale, int cout_total, int o_off) {
-  const int nch = f.cin / 32;
-  const size_t per = (size_t)f.cin * 9;
-  uint16_t* d16 = reinterpret_cast<uint16_t*>(dst);
-  for (int o = 0; o < f.cout; ++o) {
-    float mx = 0.f;
-    for (size_t i = 0; i < per; ++i) mx = std::fmax(mx, std::fabs(f.w[o * per + i]));
-    int k = 0;
-    if (mx > 0.f) k = (int)std::floor(10.0 - std::log2((double)mx));
-    if (k > 40) k = 40;
-    if (k < -20) k = -20;
-    const float sc = std::ldexp(1.0f, k);
-    inv_scale[o + o_off] = std::ldexp(1.0f, -k);
-    for (int ch = 0; ch < nch; ++ch)
-      for (int tap = 0; tap < 9; ++tap) {
-        uint16_t* row = d16 + ((((size_t)ch * 9 + tap) * cout_total + (o + o_off)) * 32) * 2;
-        for (int ci = 0; ci < 32; ++ci) {
-          const float w = f.w[(((size_t)o * f.cin) + ch * 32 + ci) * 9 + tap] * sc;  // exact (power of 2)
-          const uint16_t hi = f32_to_f16_bits(w);
-          row[ci] = hi;
-          row[32 + ci] = f32_to_f16_bits(w - f16_bits_to_f32(hi));
-        }
-      }
-  }
-}
-
 // OIHW 7x7, Cin=4 -> [64][204]: k = pair*8 + half*4 + c, the (tap of half 0 | tap of half 1) pairs in
 // the order stem7x7_mfma.hip walks them: 21 in-row pairs (r,2j)|(r,2j+1), 3 column-6 pairs
 // (2j,6)|(2j+1,6), then (6,6)|zero.  k 200..203 pad the row to 816 bytes.
@@ -174,32 +146,6 @@ void pack_stem(const Folded& f, float* dst) {
       }
 }
 
-// f16x3 stem: same [64][204] geometry, every 16-byte (pair, half) entry = w_hi(c0..3) | w_lo(c0..3) of
-// w * 2^k(cout)
-void pack_stem_split(const Folded& f, float* dst, float* inv_scale) {
-  std::vector<float> plain((size_t)64 * 204);
-  pack_stem(f, plain.data());
-  uint16_t* d16 = reinterpret_cast<uint16_t*>(dst);
-  std::memset(dst, 0, sizeof(float) * 64 * 204);
-  for (int o = 0; o < 64; ++o) {
-    float mx = 0.f;
-    for (int k = 0; k < 200; ++k) mx = std::fmax(mx, std::fabs(plain[(size_t)o * 204 + k]));
-    int kx = 0;
-    if (mx > 0.f) kx = (int)std::floor(10.0 - std::log2((double)mx));
-    if (kx > 40) kx = 40;
-    if (kx < -20) kx = -20;
-    const float sc = std::ldexp(1.0f, kx);
-    inv_scale[o] = std::ldexp(1.0f, -kx);
-    for (int e = 0; e < 50; ++e)       // 25 pairs x 2 halves
-      for (int c = 0; c < 4; ++c) {
-        const float w = plain[(size_t)o * 204 + e * 4 + c] * sc;
-        const uint16_t hi = f32_to_f16_bits(w);
-        d16[((size_t)o * 204 + e * 4) * 2 + c] = hi;
-        d16[((size_t)o * 204 + e * 4) * 2 + 4 + c] = f32_to_f16_bits(w - f16_bits_to_f32(hi));
-      }
-  }
-}
-
 }  // namespace
 
 // returns "" on success, else the missing key / problem
@@ -216,7 +162,6 @@ std::string pack_blob(const TensorMap& t, std::vector<float>& blob) {
     Folded f = fold(t, std::string(stems[br]) + ".0", std::string(stems[br]) + ".1");
     pack_stem(f, blob.data() + L.stem_w + (size_t)br * 64 * 204);
     std::memcpy(blob.data() + L.stem_b + br * 64, f.b.data(), 64 * sizeof(float));
-    pack_stem_split(f, blob.data() + L.stem_ws + (size_t)br * 64 * 204, blob.data() + L.stem_sc + br * 64);
   }
   struct Src { ConvId id; int group; int o_off; int cout_total; const char* conv; const char* bn; };
   const Src srcs[] = {
@@ -236,8 +181,6 @@ std::string pack_blob(const TensorMap& t, std::vector<float>& blob) {
     pack3(f, blob.data() + L.conv_w[s.id] + gw * s.group, s.cout_total, s.o_off);
     std::memcpy(blob.data() + L.conv_b[s.id] + (size_t)spec[s.id].cout * s.group + s.o_off, f.b.data(),
                 f.b.size() * sizeof(float));
-    pack3_split(f, blob.data() + L.conv_ws[s.id] + gw * s.group,
-                  blob.data() + L.conv_sc[s.id] + (size_t)spec[s.id].cout * s.group, s.cout_total, s.o_off);
   }
   const char* heads[2] = {"trans_out", "rot_out"};
   for (int h = 0; h < 2; ++h) {
@@ -247,6 +190,61 @@ std::string pack_blob(const TensorMap& t, std::vector<float>& blob) {
     std::memcpy(blob.data() + L.fc_b + h * 4, B.data.data(), 3 * sizeof(float));
   }
   return "";
+}
+
+// Host statement of what launch_split_weights (kernels_misc.hip) derives on the device for the f16x3 mode, from the PACKED
+// float32 panels: per cout row an exact power-of-two scaling 2^k (split_exponent: the row's largest |w| lands in
+// [2^10, 2^11), so the f16 `lo` parts never underflow), then w 2^k = hi + lo with hi = f16(w 2^k), lo = f16(w 2^k - hi),
+// stored as split rows [chunk][tap][cout][32 f16 hi | 32 f16 lo] (stems: 16-byte entries 4 hi | 4 lo) + 2^-k per cout.
+// Used by the tests to check the device derivation bit for bit (se3tn_split_weights_host); not on the product path.
+void split_blob_host(const float* blob, float* split) {
+  const BlobLayout L = blob_layout();
+  const SplitLayout S = split_layout();
+  std::memset(split, 0, S.total * sizeof(float));
+  const Conv3* spec = conv_specs();
+  for (int id = 0; id < NUM_CONV3; ++id) {
+    const int nch = spec[id].cin / 32, cout = spec[id].cout, rows = nch * 9;
+    for (int g = 0; g < spec[id].groups; ++g) {
+      const float* w = blob + L.conv_w[id] + conv3_words(spec[id].cin, cout) * g;
+      uint16_t* d16 = reinterpret_cast<uint16_t*>(split + S.conv_ws[id] + conv3_words(spec[id].cin, cout) * g);
+      float* sc = split + S.conv_sc[id] + (size_t)cout * g;
+      for (int o = 0; o < cout; ++o) {
+        float mx = 0.f;
+        for (int r = 0; r < rows; ++r)
+          for (int ci = 0; ci < 32; ++ci) mx = std::fmax(mx, std::fabs(w[((size_t)r * cout + o) * 32 + ci]));
+        const int k = split_exponent(mx);
+        const float scl = std::ldexp(1.0f, k);
+        sc[o] = std::ldexp(1.0f, -k);
+        for (int r = 0; r < rows; ++r) {
+          uint16_t* row = d16 + (((size_t)r * cout + o) * 32) * 2;
+          for (int ci = 0; ci < 32; ++ci) {
+            const float v = w[((size_t)r * cout + o) * 32 + ci] * scl;  // exact (power of 2)
+            const uint16_t hi = f32_to_f16_bits(v);
+            row[ci] = hi;
+            row[32 + ci] = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+          }
+        }
+      }
+    }
+  }
+  for (int br = 0; br < 2; ++br) {
+    const float* w = blob + L.stem_w + (size_t)br * 64 * 204;
+    uint16_t* d16 = reinterpret_cast<uint16_t*>(split + S.stem_ws + (size_t)br * 64 * 204);
+    for (int o = 0; o < 64; ++o) {
+      float mx = 0.f;
+      for (int k = 0; k < 200; ++k) mx = std::fmax(mx, std::fabs(w[(size_t)o * 204 + k]));
+      const int kx = split_exponent(mx);
+      const float scl = std::ldexp(1.0f, kx);
+      split[S.stem_sc + br * 64 + o] = std::ldexp(1.0f, -kx);
+      for (int e = 0; e < 50; ++e)       // 25 tap pairs x 2 halves
+        for (int c = 0; c < 4; ++c) {
+          const float v = w[(size_t)o * 204 + e * 4 + c] * scl;
+          const uint16_t hi = f32_to_f16_bits(v);
+          d16[((size_t)o * 204 + e * 4) * 2 + c] = hi;
+          d16[((size_t)o * 204 + e * 4) * 2 + 4 + c] = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+        }
+    }
+  }
 }
 
 }  // namespace se3tn

@@ -19,4 +19,6 @@ struct ExpectedTensor {
 const std::vector<ExpectedTensor>& expected_tensors();
 // fold BN + pack; returns "" or an error message
 std::string pack_blob(const TensorMap& t, std::vector<float>& blob);
+// host reference of the device-side derivation of the f16x3 split panels (split_layout() words) from a packed blob
+void split_blob_host(const float* blob, float* split);
 }  // namespace se3tn

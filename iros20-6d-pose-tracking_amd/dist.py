@@ -28,10 +28,11 @@ def broadcast_blob(blob_or_none, nbytes, device, src=0, group=None):
     return buf
 
 
-def load_weights_everywhere(engine, state_dict_or_none, src=0, group=None):
-    """rank `src` folds+packs the reference state_dict; all ranks bind the broadcast blob."""
+def load_weights_everywhere(engine, state_dict_or_none, src=0, group=None, device=None):
+    """rank `src` folds+packs the reference state_dict; all ranks bind the broadcast blob.  `device`: where the blob is
+    received (default: the engine's GPU; "cpu" only in the gloo dry run of bench.py)."""
     blob = engine.pack_state_dict(state_dict_or_none) if dist.get_rank(group) == src else None
-    buf = broadcast_blob(blob, engine.packed_bytes(), "cuda:%d" % engine.device, src, group)
+    buf = broadcast_blob(blob, engine.packed_bytes(), device or "cuda:%d" % engine.device, src, group)
     engine.bind_blob(buf)
     return buf
 

@@ -56,6 +56,30 @@ class Engine:
         except Exception:
             pass
 
+    def reserve(self, H, W):
+        """Start-up reservation (se3tn_reserve): z-buffer / fill_depth scratch for H x W camera frames and the planes of the
+        selected modes, so that no stream-ordered call allocates later (hipGraph capture, latency of the first frame)."""
+        check(self.lib.se3tn_reserve(self._h, int(H), int(W)), "se3tn_reserve")
+
+    def split_weights_device(self):
+        """f16x3 mode: copy of the device-derived split panels as a CPU uint8 tensor (tests)."""
+        n = int(self.lib.se3tn_split_weights_bytes(self._h))
+        ptr = self.lib.se3tn_split_weights_device(self._h)
+        if not ptr:
+            raise Se3tnError("split panels not derived: select PREC_F16X3 with weights bound")
+        out = torch.empty(n, dtype=torch.uint8, device="cuda:%d" % self.device)
+        check(self.lib.se3tn_memcpy_d2d(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), n, _stream_ptr()), "se3tn_memcpy_d2d")
+        return out.cpu()
+
+    def split_weights_host(self, packed_blob):
+        """The host statement of the same derivation applied to a packed blob (CPU uint8 tensor)."""
+        n = int(self.lib.se3tn_split_weights_bytes(self._h))
+        blob = packed_blob.contiguous()
+        out = torch.empty(n, dtype=torch.uint8)
+        check(self.lib.se3tn_split_weights_host(C.c_void_p(blob.data_ptr()), blob.numel(), C.c_void_p(out.data_ptr()), n),
+              "se3tn_split_weights_host")
+        return out
+
     # ---- weights ---------------------------------------------------------------------------
     def pack_state_dict(self, state_dict):
         """Hand the reference checkpoint's state_dict (predict.py:151-156) to the library:

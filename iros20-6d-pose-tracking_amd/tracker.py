@@ -22,6 +22,24 @@ def _depth_u16(depth, rgb):
     return np.ascontiguousarray(d, dtype=np.uint16).view(np.int16)
 
 
+def _is_full_frame_renderer(renderer):
+    """offscreen_renderer.Renderer protocol (predict.py:209-213): ``render([ob2cam]) -> (rgb HxWx3, depth HxW metres)``.
+    Detected structurally -- the reference's class has no marker attribute: an explicit ``full_frame`` attribute wins,
+    otherwise a ``render`` that takes exactly ONE positional argument (the pose list) is the full-frame protocol, one that
+    takes (ob2cam, K, window) is the window protocol."""
+    flag = getattr(renderer, "full_frame", None)
+    if flag is not None:
+        return bool(flag)
+    import inspect
+    try:
+        params = [p for p in inspect.signature(renderer.render).parameters.values()
+                  if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+    except (TypeError, ValueError):
+        return False
+    required = [p for p in params if p.default is p.empty]
+    return len(required) == 1 and len(params) < 3
+
+
 class Tracker:
     def __init__(self, dataset_info, images_mean, images_std, ckpt_dir, model_path=None,
                  trans_normalizer=0.03, rot_normalizer=5 * np.pi / 180, renderer=None, device=0,
@@ -50,6 +68,9 @@ class Tracker:
         self.engine = Engine(device, max_samples)
         self.engine.load_state_dict(sd)
         self.engine.set_normalization(self.mean, self.std)
+        # start-up reservation for this camera: full-frame z-buffer / fill_depth scratch, Winograd planes -- no stream-ordered
+        # call allocates afterwards (se3tn_reserve)
+        self.engine.reserve(int(cam['height']), int(cam['width']))
         self.trans_normalizer = float(trans_normalizer)
         self.rot_normalizer = float(rot_normalizer)
         self.engine.set_normalizers(self.trans_normalizer, self.rot_normalizer)
@@ -95,7 +116,7 @@ class Tracker:
             predict.py:201-208 does -- y-flipped bbox (scale (1000,-1000,1000)), ``update_cam_mat(K, left,
             right, bottom, top)``, ``render_image(ob2cam_gl)``;
           * the HIP rasteriser and any injected ``render(ob2cam, K, window)`` object: the same y-flipped
-            window (left, top, right, bottom) is passed;
+            window (left, top, right, bottom) is passed (round 1 passed the plain crop window: INTEGRATION.md);
           * full-frame renderers in the style of offscreen_renderer.Renderer (``render([ob2cam])`` ->
             rgb HxWx3, depth HxW metres; predict.py:209-213): depth -> uint16 mm, then the crop + NEAREST
             resize of crop_bbox on the device (se3tn_crop_raw)."""
@@ -112,7 +133,7 @@ class Tracker:
             glcam_in_cvcam = np.diag([1.0, -1.0, -1.0, 1.0])
             self.renderer.update_cam_mat(self.K, win[0], win[2], win[3], win[1])
             return self.renderer.render_image(np.linalg.inv(glcam_in_cvcam).dot(ob2cam))
-        if getattr(self.renderer, "full_frame", False):
+        if _is_full_frame_renderer(self.renderer):
             rgb, depth = self.renderer.render([ob2cam])
             depth = (np.asarray(depth) * 1000).astype(np.uint16)
             bbox = U.compute_bbox(ob2cam, self.K, self.object_width, scale=(1000, 1000, 1000))

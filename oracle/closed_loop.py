@@ -5,13 +5,26 @@ feedback, the HIP rasteriser producing image A every frame, checked frame by fra
 TEST INFRASTRUCTURE ONLY (imports the oracle).  Used by tests/test_closed_loop.py and, as the checker, by
 bench.py's `track` block; never by the product package.
 
-Per frame f with the tracker's own previous pose P_f (teacher-forced: errors cannot compound chaotically and
-every frame is a full-strength check):
-    HIP:     P_{f+1} = tracker.on_track(P_f, rgb_f, depth_f)         (render -> crop -> normalise -> CNN -> pose)
+Per frame f, with P_f the pose fed in:
+    HIP:     Q_f = tracker.on_track(P_f, rgb_f, depth_f)             (render -> crop -> normalise -> CNN -> pose)
     oracle:  O.on_track(sd, P_f, rgb_f, depth_f, rgbA_f, depthA_f)   fed the SAME rendered image A (read back)
     checks:  integer bbox identical (the only discrete decisions on the path),
-             |d(trans, rot)| <= 1e-4, |d pose| <= 1e-5  (the north-star tolerances).
-The loop of predict.py:529-564: prev_pose <- cur_pose, no re-initialisation -- except the safety net below."""
+             |d logits| (pre-tanh), |d(trans, rot)| <= 1e-4, |d pose| <= 1e-5  (the north-star tolerances).
+    feedback (the loop of predict.py:529-564, prev_pose <- cur_pose, plus what keeps a random-init net in the frustum):
+             R_{f+1} = R(Q_f)                          rotation: fully fed back, accumulates over the whole run
+             t_{f+1} = S_{f+1} + (t(Q_f) - t(P_f))     translation: the network's own step, carried onto a seeded smooth
+                                                       anchor trajectory S (a random-init network has no reason to stay on
+                                                       the object; unanchored it leaves the frustum within ~30 frames)
+Every frame is teacher-forced on the TRACKER's pose, so oracle and tracker always see the same P_f and errors do not compound.
+
+What makes the check non-vacuous (with a tiny head gain tanh(W h + b) ~ b, an input-independent constant):
+  * the FC gain is 600 x the old one and the FC biases are re-centred on a calibration set (bias := -mean logit over
+    N_CALIB frames, computed by the ORACLE), so the tanh outputs spread over roughly +-0.5 instead of sitting at a constant;
+  * the observed frames are structured images (fixtures.structured_frame), the anchor moves the crop window over them and
+    changes its size (z from 0.65 to 0.95 m), the rotation wanders -> pooled features differ frame to frame;
+  * the run reports `median_abs_trans_rot` and `std_trans_rot` (spread of the outputs over the frames) and the test asserts both;
+  * two normaliser regimes: YCB-Video (0.03 m, 5 deg: predict.py:128 defaults) and YCBInEOAT (0.03 m, 30 deg: predict.py:586),
+    where a logit error is amplified 6 x into the pose and the 1e-5 pose tolerance is the binding one."""
 import time
 
 import numpy as np
@@ -20,39 +33,85 @@ from . import fixtures as Fx
 from . import se3_oracle as O
 
 OBJECT_WIDTH_MM = 150.0
-HEAD_GAIN = 0.00002      # random-init FC gain: ~0.5 mm / 0.08 deg of pose change per frame, 300 frames stay in the frustum
+HEAD_GAIN = 0.012        # random-init FC gain: logits spread ~0.07-0.4 over the frames once centred (see module docstring)
 N_DISTINCT_FRAMES = 16   # the observed frames cycle through this many synthetic 480x640 RGB-D images
+N_CALIB = 12             # frames of the bias calibration (oracle only)
+REGIMES = {              # name -> (trans_normalizer [m], rot_normalizer [rad])
+    "ycb_video_5deg": (0.03, 5 * np.pi / 180),      # predict.py:128 defaults (predictSequenceYcb, :474)
+    "ycbineoat_30deg": (0.03, 30 * np.pi / 180),    # predict.py:586
+}
+
+
+def anchor(f):
+    """Seeded smooth anchor trajectory S_f (metres, camera frame): stays inside the frustum, sweeps the crop window over
+    the frame and changes its size."""
+    return np.array([0.07 * np.sin(2 * np.pi * f / 97.0 + 0.3), 0.045 * np.sin(2 * np.pi * f / 61.0 + 1.0),
+                     0.80 + 0.15 * np.sin(2 * np.pi * f / 131.0)])
 
 
 def _lost(P):
-    """A random-init network has no reason to stay on the object: if the pose drifts out of the region where the
-    crop window is well defined, the driver re-detects (resets to the initial pose), as a real system would."""
+    """Safety net: a pose outside the region where the crop window is well defined is re-detected (reset to the anchor)."""
     t = P[:3, 3]
     return not (abs(t[0]) < 0.25 and abs(t[1]) < 0.2 and 0.45 < t[2] < 1.3)
 
 
-def make_tracker(se3, subdiv=5, precision=None):
+def _initial_pose():
+    P = Fx.pose(3, (0.0, 0.0, 0.8))
+    P[:3, 3] = anchor(0)
+    return P
+
+
+def _frames():
+    return [Fx.structured_frame(400 + i) for i in range(N_DISTINCT_FRAMES)]
+
+
+def make_tracker(se3, subdiv=5, precision=None, regime="ycb_video_5deg", seq=None):
+    """Tracker with random-init weights whose FC biases are centred on a calibration set (so that the outputs are not a
+    saturated constant).  The calibration runs the ORACLE on N_CALIB (pose, frame) pairs with the image A the HIP
+    rasteriser renders for those poses; it only chooses the weights both sides then use."""
     from . import raster_oracle as R
     mean, std = Fx.mean_std(0)
+    tn, rn = REGIMES[regime]
     sd = O.make_state_dict(0, head_gain=HEAD_GAIN)
-    for k in ("trans_out.0.bias", "rot_out.0.bias"):     # the FC biases alone would move the pose 1.5 mm per frame
-        sd[k] = sd[k] * 0.1
     mesh = R.icosphere(subdiv, 0.06, 0)                   # 20 * 4^subdiv faces
-    trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=OBJECT_WIDTH_MM), mean, std, {"state_dict": sd})
+    trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=OBJECT_WIDTH_MM), mean, std, {"state_dict": sd},
+                      trans_normalizer=tn, rot_normalizer=rn)
     trk.renderer = se3.HipRenderer(trk.engine, mesh)
+    seq = seq or _frames()
+    logits = []
+    for i in range(N_CALIB):
+        P = Fx.pose(100 + i, tuple(anchor(25 * i)))
+        rgbA, depthA = trk.render_window(P)
+        rgb, depth = seq[i % N_DISTINCT_FRAMES]
+        _, aux = O.on_track(sd, P, rgb, depth, np.asarray(rgbA), np.asarray(depthA).view(np.uint16), trk.K,
+                            trk.object_width, mean, std, tn, rn)
+        logits.append(np.r_[aux["trans_logit"], aux["rot_logit"]])
+    centre = np.mean(logits, 0).astype(np.float32)
+    import torch
+    sd["trans_out.0.bias"] = sd["trans_out.0.bias"] - torch.from_numpy(centre[:3])
+    sd["rot_out.0.bias"] = sd["rot_out.0.bias"] - torch.from_numpy(centre[3:])
+    trk.engine.load_state_dict(sd)
     if precision is not None:
         trk.engine.set_precision(precision)
     return trk, sd, (mean, std), len(mesh["faces"])
 
 
-def run(se3, frames=300, check=True, subdiv=5, precision=None, timing=True):
-    """Returns the `track` block of the bench line."""
-    trk, sd, (mean, std), nfaces = make_tracker(se3, subdiv, precision)
-    seq = [Fx.synthetic_frame(400 + i) for i in range(N_DISTINCT_FRAMES)]
-    P0 = Fx.pose(3, (0.02, -0.01, 0.8))
-    out = {"frames": frames, "renderer": "HIP rasteriser, %d-face vertex-colour mesh, image A stays on the device" % nfaces,
-           "sequence": "synthetic 480x640 RGB-D frames (%d distinct, cycled), random-init weights, pose feedback "
-                       "frame to frame" % N_DISTINCT_FRAMES}
+def _next_pose(P, Q, f):
+    """Feedback rule of the module docstring."""
+    N = Q.copy()
+    N[:3, 3] = anchor(f + 1) + (Q[:3, 3] - P[:3, 3])
+    if _lost(N):
+        N[:3, 3] = anchor(f + 1)
+        return N, 1
+    return N, 0
+
+
+def run_regime(se3, regime, frames=300, check=True, subdiv=5, precision=None, timing=True, seq=None):
+    seq = seq or _frames()
+    trk, sd, (mean, std), nfaces = make_tracker(se3, subdiv, precision, regime, seq)
+    tn, rn = REGIMES[regime]
+    P0 = _initial_pose()
+    out = {"trans_normalizer": tn, "rot_normalizer_deg": round(rn * 180 / np.pi, 3), "frames": frames, "faces": nfaces}
     poses_timed = None
     if timing:
         P = P0.copy()
@@ -63,45 +122,83 @@ def run(se3, frames=300, check=True, subdiv=5, precision=None, timing=True):
         for f in range(frames):
             rgb, depth = seq[f % N_DISTINCT_FRAMES]
             t0 = time.perf_counter()
-            P = trk.on_track(P, rgb, depth)
+            Q = trk.on_track(P, rgb, depth)
             lat.append(time.perf_counter() - t0)
-            poses_timed.append(P)
-            if _lost(P):
-                P = P0.copy(); reinits += 1
+            poses_timed.append(Q)
+            P, r = _next_pose(P, Q, f)
+            reinits += r
         lat = np.array(lat) * 1e3
         out.update(hz=round(1000.0 / float(np.median(lat)), 1), ms_median=round(float(np.median(lat)), 4),
-                   ms_p95=round(float(np.percentile(lat, 95)), 4), reinits=reinits,
-                   includes="per frame: pageable H2D of the 480x640 frame, render, crop+normalise, CNN, pose update, "
-                            "D2H of the pose (one sync), as predict.py:217-296 without its GUI / second render")
+                   ms_p95=round(float(np.percentile(lat, 95)), 4), reinits=reinits)
     if check:
         P = P0.copy()
-        bbox_mismatch = 0
-        e_net = e_pose = 0.0
-        drift = 0.0
-        replay_diff = 0.0
-        reinits_c = 0
+        bbox_mismatch = reinits_c = 0
+        e_net = e_pose = e_logit = replay_diff = 0.0
+        outs, bboxes = [], []
+        rot_total = 0.0
         for f in range(frames):
             rgb, depth = seq[f % N_DISTINCT_FRAMES]
-            Pn = trk.on_track(P, rgb, depth)
+            Q = trk.on_track(P, rgb, depth)
+            lg = trk.engine.logits(1).cpu().numpy()[0]
             rgbA = trk.renderer.rgb.cpu().numpy()               # the image A this frame was computed from
             depthA = trk.renderer.depth.cpu().numpy().view(np.uint16)
-            want, aux = O.on_track(sd, P, rgb, depth, rgbA, depthA, trk.K, trk.object_width, mean, std,
-                                   trk.trans_normalizer, trk.rot_normalizer)
+            want, aux = O.on_track(sd, P, rgb, depth, rgbA, depthA, trk.K, trk.object_width, mean, std, tn, rn)
             bbox_mismatch += int(not np.array_equal(trk.last_prediction["bbox"], aux["bbox"]))
-            e_net = max(e_net, float(np.abs(trk.last_prediction["trans"][0] - aux["trans"]).max()),
-                        float(np.abs(trk.last_prediction["rot"][0] - aux["rot"]).max()))
-            e_pose = max(e_pose, float(np.abs(Pn - want).max()))
+            got = np.r_[trk.last_prediction["trans"][0], trk.last_prediction["rot"][0]]
+            ref = np.r_[aux["trans"], aux["rot"]]
+            e_net = max(e_net, float(np.abs(got - ref).max()))
+            e_logit = max(e_logit, float(np.abs(lg - np.r_[aux["trans_logit"], aux["rot_logit"]]).max()))
+            e_pose = max(e_pose, float(np.abs(Q - want).max()))
+            outs.append(ref)
+            bboxes.append(aux["bbox"].reshape(-1))
+            rot_total += float(np.linalg.norm(ref[3:] * np.float32(rn)))
             if poses_timed is not None:
-                replay_diff = max(replay_diff, float(np.abs(Pn - poses_timed[f]).max()))
-            drift = max(drift, float(np.linalg.norm(Pn[:3, 3] - P0[:3, 3])))
-            if _lost(Pn):
-                reinits_c += 1
-                P = P0.copy()
-            else:
-                P = Pn
-        out.update(frames_checked=frames, bbox_mismatches=bbox_mismatch, max_abs_trans_rot=e_net, max_abs_pose=e_pose,
-                   tol_trans_rot=1e-4, tol_pose=1e-5, max_drift_m=round(drift, 4), reinits_checked_pass=reinits_c,
-                   ok=bool(bbox_mismatch == 0 and e_net <= 1e-4 and e_pose <= 1e-5))
+                replay_diff = max(replay_diff, float(np.abs(Q - poses_timed[f]).max()))
+            P, r = _next_pose(P, Q, f)
+            reinits_c += r
+        signed = np.array(outs)
+        outs = np.abs(signed)
+        bboxes = np.array(bboxes)
+        out.update(frames_checked=frames, bbox_mismatches=bbox_mismatch, distinct_bboxes=int(len(np.unique(bboxes, axis=0))),
+                   max_abs_logit_diff=e_logit, max_abs_trans_rot=e_net, max_abs_pose=e_pose,
+                   median_abs_trans_rot=round(float(np.median(outs)), 4),
+                   median_abs_trans=round(float(np.median(outs[:, :3])), 4), median_abs_rot=round(float(np.median(outs[:, 3:])), 4),
+                   std_trans_rot=[round(float(v), 4) for v in signed.std(0)],
+                   max_abs_output=round(float(outs.max()), 4),
+                   accumulated_rotation_deg=round(rot_total * 180 / np.pi, 1), reinits_checked_pass=reinits_c,
+                   ok=bool(bbox_mismatch == 0 and e_net <= 1e-4 and e_logit <= 1e-4 and e_pose <= 1e-5))
         if poses_timed is not None:
             out["timed_vs_checked_pass_max_abs_pose"] = replay_diff   # the two passes are the same deterministic track
+    return out
+
+
+def run(se3, frames=300, check=True, subdiv=5, precision=None, timing=True, regimes=None):
+    """Returns the `track` block of the bench line: top-level worst-case figures over the normaliser regimes + the
+    per-regime blocks.  Hz / latency come from the first regime (the arithmetic does not depend on the normalisers)."""
+    regimes = list(regimes or REGIMES)
+    seq = _frames()
+    per = {}
+    for i, name in enumerate(regimes):
+        per[name] = run_regime(se3, name, frames, check, subdiv, precision, timing and i == 0, seq)
+    first = per[regimes[0]]
+    out = {"frames": frames,
+           "renderer": "HIP rasteriser, %d-face vertex-colour mesh, image A stays on the device" % first["faces"],
+           "sequence": "synthetic structured 480x640 RGB-D frames (%d distinct, cycled), random-init weights with calibrated FC "
+                       "biases, rotation fed back frame to frame, translation step carried on a seeded anchor trajectory"
+                       % N_DISTINCT_FRAMES}
+    if timing:
+        out.update({k: first[k] for k in ("hz", "ms_median", "ms_p95", "reinits")})
+        out["includes"] = ("per frame: pageable H2D of the 480x640 frame, render, crop+normalise, CNN, pose update, "
+                           "D2H of the pose (one sync), as predict.py:217-296 without its GUI / second render")
+    if check:
+        vals = list(per.values())
+        out.update(frames_checked=sum(v["frames_checked"] for v in vals),
+                   bbox_mismatches=sum(v["bbox_mismatches"] for v in vals),
+                   max_abs_logit_diff=max(v["max_abs_logit_diff"] for v in vals),
+                   max_abs_trans_rot=max(v["max_abs_trans_rot"] for v in vals),
+                   max_abs_pose=max(v["max_abs_pose"] for v in vals),
+                   median_abs_trans_rot=min(v["median_abs_trans_rot"] for v in vals),
+                   tol_trans_rot=1e-4, tol_pose=1e-5,
+                   ok=all(v["ok"] for v in vals))
+    out["regimes"] = per
     return out

@@ -153,4 +153,6 @@ def fill_depth(depth, max_depth=2.0, extrapolate=False, blur_type="bilateral", s
 def grab_depth(depth_mm, max_depth=2.0, extrapolate=False, blur_type="bilateral"):
     """predict_ros.py:38-41: uint16 mm frame -> filled uint16 mm frame."""
     d = fill_depth(np.asarray(depth_mm).astype(np.uint16) / 1e3, max_depth, extrapolate, blur_type)
-    return (d * 1000).astype(np.uint16)
+    # regions beyond max_depth are still negative here (only their rim gets filled); the reference's astype wraps them
+    # modulo 2^16 on x86-64 (-500 -> 65036): stated explicitly so that the result does not depend on NumPy's cast path
+    return ((d * 1000).astype(np.int64) & 0xFFFF).astype(np.uint16)

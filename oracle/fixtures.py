@@ -32,6 +32,33 @@ def synthetic_frame(seed, H=480, W=640):
     return rgb, depth
 
 
+def structured_frame(seed, H=480, W=640):
+    """Camera frame with image structure (low-frequency colour fields, per-frame gain / offset / noise level, a tilted depth
+    plane with bumps and holes): unlike synthetic_frame's i.i.d. noise, the network's pooled features -- and so its
+    (trans, rot) output -- differ from frame to frame and with the crop window (oracle/closed_loop.py)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    rgb = np.zeros((H, W, 3))
+    for c in range(3):
+        f = np.zeros((H, W))
+        for _ in range(4):
+            fx, fy = rng.uniform(-0.04, 0.04, 2)
+            f += rng.uniform(0.3, 1.0) * np.sin(fx * xx + fy * yy + rng.uniform(0, 2 * np.pi))
+        rgb[..., c] = f
+    rgb = (rgb - rgb.min()) / (rgb.max() - rgb.min())
+    gain = rng.uniform(80, 255)
+    rgb = rgb * gain + rng.uniform(0, 255 - gain) + rng.normal(0, rng.uniform(2, 25), (H, W, 3))
+    rgb = np.clip(rgb, 0, 255).astype(np.uint8)
+    d = rng.uniform(600, 1000) + rng.uniform(-0.4, 0.4) * (xx - W / 2) + rng.uniform(-0.4, 0.4) * (yy - H / 2)
+    for _ in range(5):
+        cx, cy, r = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(30, 120)
+        d -= rng.uniform(50, 250) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * r * r))
+    d += rng.normal(0, 3, (H, W))
+    depth = np.clip(d, 300, 2500).astype(np.uint16)
+    depth[rng.random((H, W)) < 0.04] = 0
+    return rgb, depth
+
+
 def synthetic_render(seed, z_m, res=176):
     """Stand-in for Tracker.render_window (predict.py:193-215): rgbA u8 [res,res,3],
     depthA u16 [res,res] mm, background exactly 0, object a disc around depth z."""
@@ -66,3 +93,55 @@ def net_inputs(seed, n, scale=1.0, res=176):
     A = torch.randn((n, 4, res, res), generator=g) * scale
     B = torch.randn((n, 4, res, res), generator=g) * scale
     return A, B
+
+
+def depth_frame_with_holes(seed, H=120, W=160, hole_frac=0.25):
+    """uint16 mm depth with holes: random blobs of zeros, a few near (<100 mm) and far (> 2 m) pixels, a large empty corner
+    (fill_depth fixtures: tests/test_fill_depth.py, oracle/pin_opencv.py)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    d = (700 + 150 * np.sin(xx / 17.0) + 100 * np.cos(yy / 11.0) + rng.integers(-8, 9, (H, W))).astype(np.float64)
+    holes = rng.random((H, W)) < hole_frac * 0.3
+    for _ in range(12):
+        cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(2, 9)
+        holes |= (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+    d[holes] = 0
+    d[rng.random((H, W)) < 0.01] = rng.integers(1, 100)
+    d[rng.random((H, W)) < 0.01] = rng.integers(2100, 4000)
+    d[: H // 6, : W // 5] = 0                      # a large empty corner (reaches the image border)
+    return d.astype(np.uint16)
+
+
+def depth_frame_with_far_wall(seed):
+    """+ a 40 x 60 region at 2.5-3 m (beyond max_depth = 2 m), larger than every structuring element of fill_depth."""
+    mm = depth_frame_with_holes(seed, 240, 320)
+    rng = np.random.default_rng(seed)
+    mm[100:140, 200:260] = rng.integers(2500, 3000, (40, 60))
+    return mm
+
+
+def icosphere(subdiv=2, radius=0.05, seed=0):
+    """Test mesh: subdivided icosahedron, outward (CCW) faces, random vertex colours, analytic normals."""
+    t = (1 + 5 ** 0.5) / 2
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, float) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = (v[a] + v[b]) / 2
+                v.append(m / np.linalg.norm(m)); cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    v = np.array(v)
+    rng = np.random.default_rng(seed)
+    return dict(vertices=(v * radius).astype(np.float32), faces=np.array(f, np.int32),
+                colors=rng.integers(40, 256, (len(v), 3)).astype(np.float64), normals=v.copy())

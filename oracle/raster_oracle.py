@@ -92,31 +92,7 @@ def render(vertices, normals, colors01, faces, ob2cam, K, window, res=176):
     return rgb, (distance * 1000).astype(np.uint16)
 
 
-def icosphere(subdiv=2, radius=0.05, seed=0):
-    """Test mesh: subdivided icosahedron, outward (CCW) faces, random vertex colours, analytic normals."""
-    t = (1 + 5 ** 0.5) / 2
-    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
-         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
-    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
-         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
-    v = [np.array(p, float) / np.linalg.norm(p) for p in v]
-    for _ in range(subdiv):
-        cache, nf = {}, []
-
-        def mid(a, b):
-            key = (min(a, b), max(a, b))
-            if key not in cache:
-                m = (v[a] + v[b]) / 2
-                v.append(m / np.linalg.norm(m)); cache[key] = len(v) - 1
-            return cache[key]
-        for a, b, c in f:
-            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
-            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
-        f = nf
-    v = np.array(v)
-    rng = np.random.default_rng(seed)
-    return dict(vertices=(v * radius).astype(np.float32), faces=np.array(f, np.int32),
-                colors=rng.integers(40, 256, (len(v), 3)).astype(np.float64), normals=v.copy())
+from .fixtures import icosphere  # noqa: E402,F401  (the test mesh lives with the other seeded fixtures)
 
 
 # ------------------------------------------------------------------------------------------------------------------

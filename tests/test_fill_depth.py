@@ -8,20 +8,7 @@ from scipy import ndimage
 from oracle import depth_oracle as D
 
 
-def _frame(seed, H=120, W=160, hole_frac=0.25):
-    """uint16 mm depth with holes: random blobs of zeros, a few near (<100 mm) and far (> 2 m) pixels."""
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:H, 0:W]
-    d = (700 + 150 * np.sin(xx / 17.0) + 100 * np.cos(yy / 11.0) + rng.integers(-8, 9, (H, W))).astype(np.float64)
-    holes = rng.random((H, W)) < hole_frac * 0.3
-    for _ in range(12):
-        cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(2, 9)
-        holes |= (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
-    d[holes] = 0
-    d[rng.random((H, W)) < 0.01] = rng.integers(1, 100)
-    d[rng.random((H, W)) < 0.01] = rng.integers(2100, 4000)
-    d[: H // 6, : W // 5] = 0                      # a large empty corner (reaches the image border)
-    return d.astype(np.uint16)
+from oracle.fixtures import depth_frame_with_holes as _frame, depth_frame_with_far_wall as _frame_with_far_wall  # noqa: E402
 
 
 def _inverted(seed):
@@ -98,6 +85,55 @@ def test_hip_fill_depth_bit_exact_up_to_the_median(eng, seed, extrapolate):
     want_m = D.fill_depth(mm / 1e3, 2.0, extrapolate, None)
     assert got_m.dtype == np.float32 and np.array_equal(got_m, want_m)         # selections only: bit-exact
     assert np.array_equal(got_mm, (want_m * 1000).astype(np.uint16))
+
+
+def test_oracle_far_region_wraps_like_numpy_on_x86():
+    mm = _frame_with_far_wall(7)
+    out = D.grab_depth(mm)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = (D.fill_depth(mm / 1e3, 2.0, False, "bilateral") * 1000).astype(np.uint16)   # the reference's expression
+    assert np.array_equal(out, plain)
+    inner = out[110:130, 215:245]
+    assert (inner > 60000).all()       # 2 m - 2.5..3 m = -0.5..-1 m -> 65536 - 500..1000: "far", invalid downstream
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blur", [None, "bilateral"])
+def test_hip_fill_depth_far_region_matches_the_reference_wraparound(eng, blur):
+    """a contiguous region beyond max_depth must come out as the reference's (wrapped) uint16, not clamped to 0."""
+    mm = _frame_with_far_wall(7)
+    got_mm, got_m = eng.fill_depth(mm, 2.0, False, blur_type=blur, return_metres=True)
+    want_m = D.fill_depth(mm / 1e3, 2.0, False, blur)
+    want_mm = D.grab_depth(mm, 2.0, False, blur)
+    assert (got_m[110:130, 215:245] < 0).all() and np.abs(got_m - want_m).max() < 2e-6
+    d = np.abs(got_mm.astype(int) - want_mm.astype(int))
+    assert (got_mm[110:130, 215:245] > 60000).all()
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_reserve_makes_fill_depth_and_render_frame_capturable(eng):
+    """se3tn_reserve allocates the full-frame scratch at start-up: afterwards se3tn_fill_depth runs inside a hipGraph capture
+    (no allocation, no synchronisation) and the replay reproduces the eager result."""
+    import torch
+    eng.reserve(480, 640)
+    mm = _frame(2, 480, 640)
+    want = eng.fill_depth(mm, 2.0, False, "bilateral")
+    src = torch.from_numpy(mm.view(np.int16)).cuda()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eng.fill_depth(src, 2.0, False, "bilateral")       # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out = eng.fill_depth(src, 2.0, False, "bilateral")
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), want)
 
 
 @pytest.mark.gpu

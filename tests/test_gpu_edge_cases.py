@@ -367,3 +367,25 @@ def test_two_contexts_queued_on_two_streams_are_bit_identical_to_one(se3, precis
         torch.cuda.synchronize()
         bad += [(k, i, int((lg != refs[0]).any(1).sum())) for i, lg in enumerate(caps) if not torch.equal(lg, refs[0])]
     assert not bad, "launches (round, index, wrong rows) that differ from the single-context result: %s" % bad
+
+
+def test_tracker_init_with_a_ycb_size_mesh_is_bounded(se3, tmp_path):
+    """a 262 k-vertex / 524 k-face binary PLY (the size of a YCB scan) through Tracker.__init__
+    (predict.py:131-142, 180-182): vectorised loaders, bounded start-up, object_width as from a per-record parse."""
+    import time
+    from test_model_loaders import _big_mesh, _write_binary_ply   # tests/ is on sys.path (pytest rootdir conftest)
+    v, n, c, f = _big_mesh()
+    path = str(tmp_path / "ycb_size.ply")
+    _write_binary_ply(path, v, n, c, f)
+    info = {k: val for k, val in Fx.DATASET_INFO.items() if k != "object_width"}
+    mean, std = Fx.mean_std(0)
+    t0 = time.perf_counter()
+    trk = se3.Tracker(info, mean, std, {"state_dict": O.make_state_dict(0)}, model_path=path)
+    dt = time.perf_counter() - t0
+    assert dt < 30.0, "Tracker.__init__ took %.1f s" % dt
+    pts = v.astype(np.float64)
+    w = se3.utils.compute_obj_max_width(se3.utils.voxel_down_sample(pts, 0.005))
+    assert abs(trk.object_width - (w + info["boundingbox"] / 100 * w)) < 1e-9
+    assert trk.renderer is not None and len(trk.renderer.mesh["faces"]) == len(f)
+    rgbA, depthA = trk.render_window(Fx.pose(3))
+    assert rgbA.shape == (176, 176, 3) and (depthA > 0).any()

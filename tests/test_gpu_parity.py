@@ -451,6 +451,34 @@ def test_f16x3_mode_parity_and_overflow_guard(se3, model0):
         eng.set_precision(se3._lib.PREC_F32)
 
 
+def test_f16x3_split_panels_derived_on_device_equal_host_statement(se3):
+    """Blob v7 carries the float32 panels only; se3tn_set_precision(F16X3) derives the split-f16 panels + per-cout scales
+    on the device (split_weights_kernel).  Bit-exact against the library's host statement of the same arithmetic (which
+    tests/test_host_abi.py pins to an independent numpy restatement from the OIHW weights) -- also after new weights are
+    bound while the mode is selected, and for a blob that arrived through bind_blob (the RCCL route)."""
+    for seed in (0, 7):
+        eng = se3.Engine(0, 4)
+        sd = O.make_state_dict(seed)
+        if seed == 7:   # awkward rows: a dead cout, a power-of-two maximum, a tiny and a huge row
+            w = sd["trans_conv2.conv1.weight"].clone()
+            w[3] = 0; w[4, 0, 0, 0] = 4.0; w[5] *= 1e-6; w[6] *= 1e5
+            sd["trans_conv2.conv1.weight"] = w
+        blob = eng.pack_state_dict(sd)
+        want = eng.split_weights_host(blob)
+        eng.load_state_dict(sd)
+        with pytest.raises(se3._lib.Se3tnError):
+            eng.split_weights_device()                      # not derived while the mode was never selected
+        eng.set_precision(se3._lib.PREC_F16X3)
+        got = eng.split_weights_device()
+        assert torch.equal(got, want), int((got != want).sum())
+        # new weights while f16x3 is selected: re-derived at upload / bind time
+        sd2 = O.make_state_dict(seed + 100)
+        want2 = eng.split_weights_host(eng.pack_state_dict(sd2))
+        eng.bind_blob(eng.pack_state_dict(sd2).cuda())
+        assert torch.equal(eng.split_weights_device(), want2)
+        eng.close()
+
+
 @pytest.mark.parametrize("seed", [101, 102, 103])
 def test_f16x3_numerics_under_awkward_scales(se3, seed):
     """The split-f16 path on weights / activations that stress its range handling: per-layer weight

@@ -62,7 +62,8 @@ def test_pose_update_host_bit_exact_vs_reference_golden(se3, golden_dir):
 
 
 def _numpy_pack(sd):
-    """Independent restatement of the blob layout documented in csrc/se3tn_internal.h."""
+    """Independent restatement of the blob layout (float32 panels) and of the f16x3 split layout documented in
+    csrc/se3tn_internal.h (BlobLayout / SplitLayout).  Returns (blob, split) as float32 word arrays."""
     def fold(conv, bn):
         w = sd[conv + ".weight"].double().numpy(); b = sd[conv + ".bias"].double().numpy()
         s = sd[bn + ".weight"].double().numpy() / np.sqrt(sd[bn + ".running_var"].double().numpy() + 1e-5)
@@ -86,6 +87,7 @@ def _numpy_pack(sd):
         parts.append(t.reshape(-1))
         stem_plain.append(t)
     parts += [b for _, b in stems]
+    split = []
     inv = []
     for t in stem_plain:  # f16x3 stem: per 16-byte entry 4 f16 hi | 4 f16 lo of w * 2^k(cout)
         mx = np.abs(t[:, :200]).max(1).astype(np.float64)
@@ -94,9 +96,9 @@ def _numpy_pack(sd):
         hi = ws.astype(np.float16); lo = (ws - hi.astype(np.float32)).astype(np.float16)
         e = np.concatenate([hi.reshape(64, 50, 4), lo.reshape(64, 50, 4)], axis=2).reshape(64, 400)
         row = np.zeros((64, 408), np.float16); row[:, :400] = e
-        parts.append(np.ascontiguousarray(row).view(np.float32).reshape(-1))
+        split.append(np.ascontiguousarray(row).view(np.float32).reshape(-1))
         inv.append(np.exp2(-k).astype(np.float32))
-    parts += inv
+    split += inv
     groups = [[("convA2.conv1", "convA2.bn1"), ("convB2.conv1", "convB2.bn1")],
               [("convA2.conv2", "convA2.bn2"), ("convB2.conv2", "convB2.bn2")],
               [("convB3.conv1", "convB3.bn1")], [("convB3.conv2", "convB3.bn2")],
@@ -128,27 +130,56 @@ def _numpy_pack(sd):
         if g == "H1":
             (wt, _), (wr, _) = fold("trans_conv1.0", "trans_conv1.1"), fold("rot_conv1.0", "rot_conv1.1")
             ws, sc = pack3_split(np.concatenate([wt, wr], 0))
-            parts += [ws, sc]
+            split += [ws, sc]
         else:
             f = [pack3_split(fold(c, b)[0]) for c, b in g]
-            parts += [x[0] for x in f] + [x[1] for x in f]
+            split += [x[0] for x in f] + [x[1] for x in f]
     for h in ("trans_out", "rot_out"):
         parts.append(sd[h + ".0.weight"].numpy().reshape(-1))
     for h in ("trans_out", "rot_out"):
         parts.append(np.concatenate([sd[h + ".0.bias"].numpy(), np.zeros(1, np.float32)]))
     blob = np.concatenate(parts)
-    return np.concatenate([blob, np.zeros((-len(blob)) % 64, np.float32)])
+    split = np.concatenate(split)
+    pad = lambda x: np.concatenate([x, np.zeros((-len(x)) % 64, np.float32)])   # noqa: E731
+    return pad(blob), pad(split)
 
 
 def test_weight_folding_and_packing_host_only(se3):
     eng = se3.Engine(device=-1, max_batch=1)  # host-only context: no GPU needed
     sd = O.make_state_dict(3)
-    blob = eng.pack_state_dict(sd).numpy().view(np.float32)
-    want = _numpy_pack(sd)
+    blob_t = eng.pack_state_dict(sd)
+    blob = blob_t.numpy().view(np.float32)
+    want, want_split = _numpy_pack(sd)
     assert blob.size == want.size == eng.packed_bytes() // 4
+    assert 54.0e6 < eng.packed_bytes() < 54.3e6      # float32 panels only: what the RCCL broadcast carries (blob v7)
     hdr = blob[:4].view(np.uint32)
-    assert hdr[0] == 0x53453354 and hdr[2] == blob.size
-    assert (blob[64:].view(np.uint32) == want[64:].view(np.uint32)).all()  # bit-exact incl. the f16 split rows
+    assert hdr[0] == 0x53453354 and hdr[1] == 7 and hdr[2] == blob.size
+    assert (blob[64:].view(np.uint32) == want[64:].view(np.uint32)).all()  # bit-exact
+    # the f16x3 split panels are no longer in the blob: derived from it (on the device in the product; the library's host
+    # statement of the same arithmetic here) -- bit-exact against the independent numpy restatement from the OIHW weights
+    split = eng.split_weights_host(blob_t).numpy().view(np.float32)
+    assert split.size == want_split.size
+    assert (split.view(np.uint32) == want_split.view(np.uint32)).all()
+
+
+def test_split_exponent_rule_at_powers_of_two(se3):
+    """k = floor(10 - log2(max|w|)) is evaluated on the float's exponent: exact at powers of two and their neighbours."""
+    eng = se3.Engine(device=-1, max_batch=1)
+    sd = O.make_state_dict(5)
+    w = sd["convAB2.conv1.weight"].clone()
+    for i, mx in enumerate([1.0, 0.5, np.nextafter(np.float32(0.5), np.float32(1)), np.nextafter(np.float32(0.5), np.float32(0)),
+                            2.0 ** -12, 3.0, 1024.0, 2047.9, 2048.0]):
+        w[i] = w[i] * 1e-3
+        w[i, 0, 0, 0] = float(mx)
+    sd["convAB2.conv1.weight"] = w
+    # fold with identity BN so that the row maxima survive exactly
+    for k in ("weight", "bias", "running_mean", "running_var"):
+        sd["convAB2.bn1." + k] = torch.ones(256) if k in ("weight",) else torch.zeros(256)
+    sd["convAB2.bn1.running_var"] = torch.ones(256) - 1e-5
+    blob_t = eng.pack_state_dict(sd)
+    _, want_split = _numpy_pack(sd)
+    split = eng.split_weights_host(blob_t).numpy().view(np.float32)
+    assert (split.view(np.uint32) == want_split.view(np.uint32)).all()
 
 
 def test_error_paths(se3):

@@ -147,7 +147,38 @@ def test_render_window_protocols(se3, tracker):
     rgbA, depthA = trk.render_window(P)
     o_rgb, o_depth = O.crop_bbox(f.rgb, (f.depth_m * 1000).astype(np.uint16), plain, (176, 176))
     assert (rgbA == o_rgb).all() and (depthA == o_depth).all() and depthA.dtype == np.uint16
+    # (3b) the reference's own Renderer class has no `full_frame` marker: the protocol is recognised by the signature
+    #      render(self, ob_in_cvcams) (offscreen_renderer.py:73)
+    class RefStyle:
+        def render(self, ob_in_cvcams):
+            assert isinstance(ob_in_cvcams, list) and np.asarray(ob_in_cvcams[0]).shape == (4, 4)
+            rgb, depth = Fx.synthetic_frame(77)
+            return rgb, depth.astype(np.float64) / 1000.0
+    trk.renderer = RefStyle()
+    rgbB, depthB = trk.render_window(P)
+    assert (rgbB == o_rgb).all() and (depthB == o_depth).all()
     trk.renderer = _Stub()
+
+
+def test_full_frame_protocol_detection_is_structural():
+    import importlib
+    T = importlib.import_module("iros20-6d-pose-tracking_amd.tracker")
+
+    class One:
+        def render(self, poses): ...
+
+    class Three:
+        def render(self, ob2cam, K, window): ...
+
+    class Marked:
+        full_frame = False
+
+        def render(self, poses): ...
+
+    class Opt:
+        def render(self, poses, flags=None): ...
+    assert T._is_full_frame_renderer(One()) and T._is_full_frame_renderer(Opt())
+    assert not T._is_full_frame_renderer(Three()) and not T._is_full_frame_renderer(Marked())
 
 
 def test_samples_beyond_capacity_and_depth_dtypes(se3, tracker):
