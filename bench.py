@@ -781,78 +781,186 @@ def cpu_model():
     return model, max(1, len(sockets))
 
 
+def physical_cores():
+    """One logical CPU per physical core of this process's affinity mask, ordered by (package, core): SMT siblings are
+    left idle (two oneDNN threads on one core run slower than one)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, out = set(), []
+    for c in allowed:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+            pkg = int(open("/sys/devices/system/cpu/cpu%d/topology/physical_package_id" % c).read())
+        except OSError:
+            sib, pkg = str(c), 0
+        if (pkg, sib) in seen:
+            continue
+        seen.add((pkg, sib))
+        out.append((pkg, c))
+    return [c for _, c in sorted(out)]
+
+
+def _cpu_worker(cpus, threads, seconds, chunk, start, q):
+    """One pinned oracle process of the cpu_baseline: the WHOLE per-pair path (crop_bbox + processData on numpy, the network
+    on torch-CPU in forwards of `chunk` pairs, processPredict), for `seconds` after a common start."""
+    try:
+        os.sched_setaffinity(0, cpus)
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        import numpy as np
+        import torch
+        torch.set_num_threads(threads)
+        from oracle import fixtures as Fx
+        from oracle import se3_oracle as O
+        sd = O.make_state_dict(0)
+        mean, std = Fx.mean_std(0)
+        rgb, depth = Fx.synthetic_frame(3); P = Fx.pose(3); rgbA, depthA = Fx.synthetic_render(103, 0.8)
+
+        def one_chunk():
+            a_, b_ = [], []
+            for _ in range(chunk):
+                bb = O.compute_bbox(P, Fx.K_YCB, 250.0, (1000, 1000, 1000))
+                rgbB, depthB = O.crop_bbox(rgb, depth, bb, (176, 176))
+                a, b = O.process_data(rgbA, depthA, P, rgbB, depthB, mean, std)
+                a_.append(a); b_.append(b)
+            out = O.forward(sd, torch.from_numpy(np.stack(a_)), torch.from_numpy(np.stack(b_)))
+            for i in range(chunk):
+                O.process_predict(P, out["trans"][i].numpy(), out["rot"][i].numpy())
+        one_chunk()
+        q.put(("ready", 0))
+        if not start.wait(timeout=300):
+            return
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < seconds:
+            one_chunk(); n += chunk
+        q.put((n, time.perf_counter() - t0))
+    except Exception as e:   # noqa: BLE001
+        q.put(("error", repr(e)))
+
+
+def cpu_multiprocess_rate(procs, threads, seconds, chunk, cores):
+    """`procs` pinned oracle processes x `threads` threads, disjoint blocks of physical cores, common start (barrier);
+    returns whole-path pairs/s = all pairs finished / the slowest worker's time."""
+    import multiprocessing as mp
+    import queue as queue_mod
+    ctx = mp.get_context("spawn")
+    start, q = ctx.Event(), ctx.Queue()
+    ws = [ctx.Process(target=_cpu_worker, args=(set(cores[i * threads:(i + 1) * threads]), threads, seconds, chunk, start, q))
+          for i in range(procs)]
+    for w in ws:
+        w.start()
+
+    def collect(n, deadline):
+        got = []
+        while len(got) < n:
+            try:
+                got.append(q.get(timeout=1.0))
+            except queue_mod.Empty:
+                if time.time() > deadline or not all(w.is_alive() or w.exitcode == 0 for w in ws):
+                    return got, "a worker died or timed out"
+                continue
+            if got[-1][0] == "error":
+                return got, str(got[-1][1])
+        return got, None
+    _, err = collect(procs, time.time() + 240)          # every worker imported torch, pinned itself and warmed up
+    res = []
+    if err is None:
+        start.set()                                     # common start
+        res, err = collect(procs, time.time() + seconds + 120)
+    for w in ws:
+        if err is not None:
+            w.kill()
+        w.join(timeout=30)
+    if err is not None:
+        return None, err
+    return sum(r[0] for r in res) / max(r[1] for r in res), None
+
+
 def cpu_baseline(O, sd, nb, inputs=None):
-    """The CPU oracle (torch-CPU fp32 restatement of the reference network + numpy pre/post) timed
-    on this box's host cores on a bounded sample (~10-25 s)."""
+    """The CPU oracle (torch-CPU fp32 restatement of the reference network + numpy pre/post) timed on this box's host cores
+    on a bounded sample (~40 s).  `value` = the BEST whole-path configuration measured in THIS run (every configuration is
+    timed once, for the same duration, and the reported figure is that measurement -- never a sweep winner re-timed):
+    single process with 16 / 32 / 64 threads, and K pinned processes x T threads on disjoint physical cores (a single oneDNN
+    process cannot use a 2 x 64-core box: 256 threads -> ~1 pair/s).  Batch 1 (what the reference's live tracker runs) beside it."""
     import numpy as np
     import torch
     from oracle import fixtures as Fx
     ncpu = os.cpu_count() or 1
     model, sockets = cpu_model()
+    cores = physical_cores()
+    P = len(cores)
     A, B = inputs if inputs is not None else Fx.net_inputs(3, nb)
-    # oneDNN collapses when over-subscribed (256 threads on the 2x64-core EPYC box: a few pairs/s): sweep the
-    # thread count on 16 pairs, time the sample with the best one, and report the all-cores figure beside it
-    sweep, best, cores = {}, None, ncpu
-    for th in sorted({max(1, ncpu // 8), max(1, ncpu // 4), max(1, ncpu // 2), ncpu}):
+    SECONDS, CHUNK = 4.0, 16
+    mean, std = Fx.mean_std(0)
+    rgb, depth = Fx.synthetic_frame(3); Pz = Fx.pose(3); rgbA, depthA = Fx.synthetic_render(103, 0.8)
+    t0 = time.perf_counter()
+    for _ in range(8):
+        bb = O.compute_bbox(Pz, Fx.K_YCB, 250.0, (1000, 1000, 1000))
+        rgbB, depthB = O.crop_bbox(rgb, depth, bb, (176, 176))
+        O.process_data(rgbA, depthA, Pz, rgbB, depthB, mean, std)
+        O.process_predict(Pz, np.zeros(3, np.float32), np.zeros(3, np.float32))
+    pp_s_per_pair = (time.perf_counter() - t0) / 8
+    configs = {}
+    # single process: network on the timed batch's own pairs in forwards of 16, + the measured numpy pre/post per pair
+    old_aff = os.sched_getaffinity(0)
+    for th in sorted({t for t in (16, 32, 64) if t <= P} or {P}):
+        try:
+            os.sched_setaffinity(0, set(cores[:th]))
+        except OSError:
+            pass
         torch.set_num_threads(th)
-        O.forward(sd, A[:4], B[:4])
-        t0 = time.perf_counter(); O.forward(sd, A[:16], B[:16]); dt = time.perf_counter() - t0
-        sweep[th] = round(16.0 / dt, 2)
-        if best is None or dt < best:
-            best, cores = dt, th
-    torch.set_num_threads(cores)
-    O.forward(sd, A[:8], B[:8])  # warm-up
-    # the batch as ONE forward or in chunks of 16 (oneDNN's per-pair rate drops at batch 64 on this box): the CPU gets
-    # whichever is faster
-    chunk = nb
-    if nb > 16:
-        t0 = time.perf_counter(); O.forward(sd, A, B); t_whole = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        for c0 in range(0, nb, 16):
-            O.forward(sd, A[c0:c0 + 16], B[c0:c0 + 16])
-        if time.perf_counter() - t0 < t_whole:
-            chunk = 16
-    runs, t_net = 0, 0.0
-    while t_net < 8.0 and runs < 60:
-        t0 = time.perf_counter()
-        for c0 in range(0, nb, chunk):
-            O.forward(sd, A[c0:c0 + chunk], B[c0:c0 + chunk])
-        t_net += time.perf_counter() - t0; runs += 1
-    net_s_per_pair = t_net / (runs * nb)
-    # batch 1 (what the reference's live tracker runs): best of a small thread sweep, 10 forwards each
+        O.forward(sd, A[:CHUNK], B[:CHUNK])
+        t0 = time.perf_counter(); n = 0; c0 = 0
+        while time.perf_counter() - t0 < SECONDS:
+            O.forward(sd, A[c0:c0 + CHUNK], B[c0:c0 + CHUNK]); n += min(CHUNK, nb - c0)
+            c0 = (c0 + CHUNK) % max(CHUNK, nb - nb % CHUNK)
+        net = n / (time.perf_counter() - t0)
+        configs["1 x %d" % th] = {"processes": 1, "threads": th, "value": round(1.0 / (1.0 / net + pp_s_per_pair), 2),
+                                  "network_only": round(net, 2)}
+    # batch 1: best of a small thread sweep, 10 forwards each
     b1 = {}
-    for th in sorted({8, 16, 32, cores}):
-        if th > ncpu:
-            continue
+    for th in sorted({t for t in (8, 16, 32) if t <= P} or {P}):
+        try:
+            os.sched_setaffinity(0, set(cores[:th]))
+        except OSError:
+            pass
         torch.set_num_threads(th)
         O.forward(sd, A[:1], B[:1])
         t0 = time.perf_counter()
         for _ in range(10):
             O.forward(sd, A[:1], B[:1])
         b1[th] = round(10.0 / (time.perf_counter() - t0), 2)
-    torch.set_num_threads(cores)
-    # pre/post (numpy, single-threaded python as in the reference): 8 pairs
-    mean, std = Fx.mean_std(0)
-    rgb, depth = Fx.synthetic_frame(3); P = Fx.pose(3); rgbA, depthA = Fx.synthetic_render(103, 0.8)
-    t0 = time.perf_counter()
-    for _ in range(8):
-        bb = O.compute_bbox(P, Fx.K_YCB, 250.0, (1000, 1000, 1000))
-        rgbB, depthB = O.crop_bbox(rgb, depth, bb, (176, 176))
-        O.process_data(rgbA, depthA, P, rgbB, depthB, mean, std)
-        O.process_predict(P, np.zeros(3, np.float32), np.zeros(3, np.float32))
-    pp_s_per_pair = (time.perf_counter() - t0) / 8
+    try:
+        os.sched_setaffinity(0, old_aff)
+    except OSError:
+        pass
+    # K pinned processes x T threads over the physical cores (whole path inside every worker)
+    errors = {}
+    for th in (16, 8, 32):
+        k = P // th
+        if k < 2:
+            continue
+        rate, err = cpu_multiprocess_rate(k, th, SECONDS, CHUNK, cores)
+        if rate is None:
+            errors["%d x %d" % (k, th)] = err
+            continue
+        configs["%d x %d" % (k, th)] = {"processes": k, "threads": th, "value": round(rate, 2)}
+    best = max(configs, key=lambda k_: configs[k_]["value"])
+    single = max((k_ for k_ in configs if configs[k_]["processes"] == 1), key=lambda k_: configs[k_]["value"])
     b1_best = max(b1, key=b1.get)
-    return {"value": round(1.0 / (net_s_per_pair + pp_s_per_pair), 2), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "cpu_model": model, "sockets": sockets, "logical_cpus": ncpu,
-            "network_only_pairs_per_s": round(1.0 / net_s_per_pair, 2),
-            "thread_sweep_pairs_per_s_batch16": sweep,
-            "all_cores_value_batch16": sweep.get(ncpu),
-            "batch1": {"value": round(1.0 / (1.0 / b1[b1_best] + pp_s_per_pair), 2), "cores": b1_best,
-                       "network_only_by_threads": b1, "unit": "pairs/s"},
-            "prepost_ms_per_pair": round(pp_s_per_pair * 1e3, 3),
-            "sample": "oracle (torch-CPU fp32 port of the reference network, %s x%d sockets, best of a thread sweep = %d of %d "
-                      "logical CPUs): %d passes over the timed batch's own %d pairs in forwards of %d (%.2f s) + 8 numpy pre/post-"
-                      "processing passes" % (model, sockets, cores, ncpu, runs, nb, chunk, t_net), "forward_chunk": chunk}
+    torch.set_num_threads(min(32, P))
+    out = {"value": configs[best]["value"], "unit": "pairs/s", "cores": configs[best]["processes"] * configs[best]["threads"],
+           "kind": "port", "configuration": best + " (processes x threads, pinned to disjoint physical cores)",
+           "cpu_model": model, "sockets": sockets, "logical_cpus": ncpu, "physical_cores": P,
+           "configurations_pairs_per_s": configs,
+           "single_process_best": {"configuration": single, "value": configs[single]["value"], "cores": configs[single]["threads"]},
+           "batch1": {"value": round(1.0 / (1.0 / b1[b1_best] + pp_s_per_pair), 2), "cores": b1_best,
+                      "network_only_by_threads": b1, "unit": "pairs/s"},
+           "prepost_ms_per_pair": round(pp_s_per_pair * 1e3, 3),
+           "sample": "oracle (torch-CPU fp32 port of the reference network + numpy crop / normalise / pose update; %s x%d sockets, "
+                     "%d physical cores): every configuration timed once for %.0f s in forwards of %d pairs; value = the best of them"
+                     % (model, sockets, P, SECONDS, CHUNK)}
+    if errors:
+        out["configurations_failed"] = errors
+    return out
 
 
 if __name__ == "__main__":

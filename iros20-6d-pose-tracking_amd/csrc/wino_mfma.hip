@@ -37,6 +37,19 @@
 #define WINO_MID_CS_H 32   // ... on the 11 x 11 maps (LDS 14 x 14 x CS floats)
 #endif
 
+#ifdef SE3TN_WG_TRACE
+// diagnostic build only (scripts/wg_trace.py): every workgroup of wino_gemm_kernel records where and when it ran
+__device__ unsigned long long se3tn_wg_trace[8 * 4096];
+extern "C" int se3tn_debug_wg_trace(void* host_out, size_t bytes, int clear) {
+  if (clear) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(se3tn_wg_trace)) != hipSuccess) return 1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 8 * 4096);
+  }
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(se3tn_wg_trace), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 namespace se3tn {
 
 // ---- Toom-Cook matrices ------------------------------------------------------------------------------
@@ -305,6 +318,32 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+#ifdef SE3TN_WG_TRACE
+  unsigned long long t_start_ = 0;
+  if (tid == 0 && blockIdx.x < 4096) {
+    t_start_ = __builtin_amdgcn_s_memrealtime();
+    unsigned hw_, xcc_;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+    ::se3tn_wg_trace[blockIdx.x * 8 + 0] = 1ull + blockIdx.x;
+    ::se3tn_wg_trace[blockIdx.x * 8 + 1] = hw_;
+    ::se3tn_wg_trace[blockIdx.x * 8 + 2] = xcc_;
+    ::se3tn_wg_trace[blockIdx.x * 8 + 3] = t_start_;
+  }
+#endif
+#ifdef SE3TN_WINO_STAGGER
+  // experiment: the two workgroups of a CU start together and, tiles being equal, stay in lock step (both in their
+  // prologue, both in their epilogue): delay one of them by about half a tile
+  {
+#if SE3TN_WINO_STAGGER == 1
+    const bool late = blockIdx.x >= 256 && blockIdx.x < 512;
+#else
+    const bool late = blockIdx.x < 512 && (blockIdx.x & 1);
+#endif
+    if (late)
+      for (int i_ = 0; i_ < (CIN == 256 ? 3 : 6); ++i_) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   ISSUE_TILE(0, 0)
   wait_dma_and_barrier();
 
@@ -327,6 +366,9 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
   }
 #undef ISSUE_TILE
 
+#ifdef SE3TN_WG_TRACE
+  if (tid == 0 && blockIdx.x < 4096) ::se3tn_wg_trace[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();   // K-loop done
+#endif
   // lane holds row l31 x couts {8 q + 4 hh + 0..3} of each 32 x 32 block
   float* __restrict__ Mb = a.Mw + (size_t)b * a.T * a.Cout;
 #pragma unroll
@@ -342,6 +384,9 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
             make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
       }
   }
+#ifdef SE3TN_WG_TRACE
+  if (tid == 0 && blockIdx.x < 4096) ::se3tn_wg_trace[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();   // stores issued
+#endif
 }
 
 

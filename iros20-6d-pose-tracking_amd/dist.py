@@ -2,7 +2,8 @@
 torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" for the CPU tests).
 
 The path is embarrassingly parallel over pairs: the only exchanges are
-  (C1) a one-off broadcast of the packed weight blob (54 MB) from rank 0, and
+  (C1) a one-off broadcast of the packed weight blob (54 MB: the BN-folded float32 panels, blob v7; every rank derives its
+       Winograd planes and, if selected, its f16x3 split panels on its own device) from rank 0, and
   (C2) a per-step all-gather of the [n_local,16] float64 poses (KBs, latency-bound).
 No all-reduce exists anywhere on the path."""
 import torch
