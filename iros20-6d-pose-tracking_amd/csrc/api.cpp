@@ -75,6 +75,10 @@ struct se3tn_ctx {
   SplitLayout SL;                               // f16x3 mode: split panels in split_w (derived from the blob, not part of it)
   float* split_w = nullptr;
   const float* split_blob = nullptr;            // the blob split_w was derived from
+  float* wino_us[4] = {nullptr, nullptr, nullptr, nullptr};   // f16x3 Winograd blocks: U as split rows ...
+  float* wino_usc[4] = {nullptr, nullptr, nullptr, nullptr};  // ... and their per-(group, frequency, cout) 2^-k
+  const float* wino_us_blob = nullptr;          // the blob / tile the split planes were derived for
+  int wino_us_tile = 0;
   int prec = SE3TN_PREC_F32;                    // se3tn_set_precision
   int in_split[2] = {0, 0};                     // pixel format currently held by inA / inB
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
@@ -147,6 +151,7 @@ static int wino_prepare(se3tn_ctx* c, hipStream_t st) {
     HIPCHK(hipStreamSynchronize(st));  // init-time
     c->wino_blob = c->blob;
     c->wino_tile_derived = c->wino_tile;
+    c->wino_us_blob = nullptr;   // the f16x3 split planes follow U
   }
   return SE3TN_OK;
 }
@@ -154,11 +159,31 @@ static int wino_prepare(se3tn_ctx* c, hipStream_t st) {
 // f16x3 mode: the split-f16 panels + per-cout scales, derived on the device from the bound float32 blob (init time: called
 // from se3tn_set_precision / se3tn_upload_weights / se3tn_bind_weights, never from a stream-ordered compute call)
 static int split_prepare(se3tn_ctx* c, hipStream_t st) {
-  if (c->device < 0 || c->prec != SE3TN_PREC_F16X3 || !c->blob || c->split_blob == c->blob) return SE3TN_OK;
-  if (!c->split_w) HIPCHK(hipMalloc((void**)&c->split_w, c->SL.total * sizeof(float)));
-  HIPCHK(launch_split_weights(c->blob, c->L, c->split_w, c->SL, st));
-  HIPCHK(hipStreamSynchronize(st));  // init-time
-  c->split_blob = c->blob;
+  if (c->device < 0 || c->prec != SE3TN_PREC_F16X3 || !c->blob) return SE3TN_OK;
+  if (c->split_blob != c->blob) {
+    if (!c->split_w) HIPCHK(hipMalloc((void**)&c->split_w, c->SL.total * sizeof(float)));
+    HIPCHK(launch_split_weights(c->blob, c->L, c->split_w, c->SL, st));
+    HIPCHK(hipStreamSynchronize(st));  // init-time
+    c->split_blob = c->blob;
+  }
+  // the fused F(4x4) blocks in f16x3 mode: split rows of U = G g G^T (derived by wino_prepare, which runs first)
+  if (c->wino_u[0] && c->wino_blob == c->blob && c->wino_tile_derived == 4 &&
+      (c->wino_us_blob != c->blob || c->wino_us_tile != 4)) {
+    for (int i = 0; i < 4; ++i) {
+      const Conv3& s = conv_specs()[kWinoConvs[i]];
+      const size_t per_g = (size_t)36 * s.cin * s.cout;
+      if (!c->wino_us[i]) {
+        HIPCHK(hipMalloc((void**)&c->wino_us[i], s.groups * per_g * sizeof(float)));
+        HIPCHK(hipMalloc((void**)&c->wino_usc[i], (size_t)s.groups * 36 * s.cout * sizeof(float)));
+      }
+      for (int g = 0; g < s.groups; ++g)
+        HIPCHK(launch_split_wino_u(c->wino_u[i] + g * per_g, c->wino_us[i] + g * per_g, c->wino_usc[i] + (size_t)g * 36 * s.cout, s.cin,
+                                   s.cout, 36, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    c->wino_us_blob = c->blob;
+    c->wino_us_tile = 4;
+  }
   return SE3TN_OK;
 }
 
@@ -252,7 +277,9 @@ void se3tn_destroy(se3tn_ctx* c) {
   if (c->device >= 0) {
     float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
                      c->head_t, c->head_f, c->logits, c->fcpart, c->part, c->blob_owned, c->split_w, c->wino_v, c->wino_m,
-                     c->wino_u[0], c->wino_u[1], c->wino_u[2], c->wino_u[3]};
+                     c->wino_u[0], c->wino_u[1], c->wino_u[2], c->wino_u[3],
+                     c->wino_us[0], c->wino_us[1], c->wino_us[2], c->wino_us[3], c->wino_usc[0], c->wino_usc[1], c->wino_usc[2],
+                     c->wino_usc[3]};
     for (float* b : bufs)
       if (b) (void)hipFree(b);
     for (auto& g : c->graphs)
@@ -308,8 +335,9 @@ int se3tn_upload_weights(se3tn_ctx* c, void* stream) {
   c->blob = c->blob_owned;
   c->wino_blob = nullptr;  // same address, new contents
   c->split_blob = nullptr;
-  if (int rc = split_prepare(c, (hipStream_t)stream)) return rc;
-  return wino_prepare(c, (hipStream_t)stream);
+  c->wino_us_blob = nullptr;
+  if (int rc = wino_prepare(c, (hipStream_t)stream)) return rc;
+  return split_prepare(c, (hipStream_t)stream);
 }
 
 int se3tn_bind_weights(se3tn_ctx* c, const void* device_blob, size_t bytes) {
@@ -322,8 +350,9 @@ int se3tn_bind_weights(se3tn_ctx* c, const void* device_blob, size_t bytes) {
   c->blob = (const float*)device_blob;
   c->wino_blob = nullptr;
   c->split_blob = nullptr;
-  if (int rc = split_prepare(c, nullptr)) return rc;
-  return wino_prepare(c, nullptr);
+  c->wino_us_blob = nullptr;
+  if (int rc = wino_prepare(c, nullptr)) return rc;
+  return split_prepare(c, nullptr);
 }
 
 int se3tn_set_winograd(se3tn_ctx* c, int min_batch, int tile) {
@@ -332,7 +361,8 @@ int se3tn_set_winograd(se3tn_ctx* c, int min_batch, int tile) {
   c->wino_min_batch = min_batch;
   if (tile) c->wino_tile = tile;
   if (c->device < 0) return SE3TN_OK;
-  return wino_prepare(c, nullptr);
+  if (int rc = wino_prepare(c, nullptr)) return rc;
+  return split_prepare(c, nullptr);
 }
 
 int se3tn_get_winograd(const se3tn_ctx* c, int* min_batch, int* tile) {
@@ -598,7 +628,8 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
   // ResnetBasicBlocks of 256 / 512 channels: at n >= wino_min_batch with F(4x4) the whole block runs through
   // launch_wino_block (conv1's out-transform fused with conv2's in-transform; the heads' last out-transform fused
   // with avg-pool + FC + tanh); otherwise conv by conv (direct / split-K / F(2x2) kernels)
-  const bool wino_block = !fast && c->wino_min_batch > 0 && n >= c->wino_min_batch && c->wino_v && c->wino_tile == 4;
+  const bool wino_block = c->wino_min_batch > 0 && n >= c->wino_min_batch && c->wino_v && c->wino_tile == 4 &&
+                          (!fast || (c->wino_us_blob == c->blob && c->wino_us_tile == 4));
   struct MarkCtx { se3tn_ctx* c; hipStream_t st; const char* name; };
   auto mark_fn = [](void* p) -> int { MarkCtx* m = (MarkCtx*)p; return prof_mark(m->c, m->st, m->name, true); };
   auto block = [&](ConvId id1, ConvId id2, float* io, float* mid, int ld, int gs, int hin, const TailArgs* tl,
@@ -614,13 +645,23 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
     w.C = s.cin; w.Cout = s.cout; w.groups = s.groups;
     w.in_gs = gs; w.res_gs = gs; w.out_gs = gs; w.bias_gs = s.cout;
     w.u_gs = (long long)w.nf * s.cin * s.cout;
+    const float *U2 = c->wino_u[wino_slot(id2)], *usc2 = nullptr;
+    float* keep2 = (tl && c->keep_intermediates) ? io : nullptr;
+    if (fast) {   // f16x3: split-row activations / V / U, float32 M
+      w.split = 1;
+      w.U = c->wino_us[wino_slot(id1)]; w.uscale = c->wino_usc[wino_slot(id1)];
+      U2 = c->wino_us[wino_slot(id2)]; usc2 = c->wino_usc[wino_slot(id2)];
+      w.overflow = c->overflow;
+      if (keep2) keep2 = c->head_f;   // the kept head activation is float32 (head itself holds split rows)
+    }
     MarkCtx mc{c, st, name1};
-    hipError_t e = launch_wino_block(w, c->wino_u[wino_slot(id2)], W + L.conv_b[id2], io, c->keep_intermediates ? 1 : 0,
-                                     (tl && c->keep_intermediates) ? io : nullptr, tl, st, mark_fn, &mc);
+    hipError_t e = launch_wino_block(w, U2, usc2, W + L.conv_b[id2], io, c->keep_intermediates ? 1 : 0, keep2, tl, st, mark_fn, &mc);
     if (e != hipSuccess) return hipfail(e, name2);
     return prof_mark(c, st, name2, true);
   };
-  if (wino_block) {
+  // f16x3 mode: the batched GEMMs of the 256-channel block are bandwidth-bound at the f16 matrix rate (41 FLOP per byte of V / M
+  // traffic) and lose to the direct f16x3 kernels (0.247 vs 0.220 ms at batch 64); the 512-channel heads win (0.349 vs 0.427 ms)
+  if (wino_block && !fast) {
     if ((rc = block(LAB2_1, LAB2_2, c->ab, c->ab_t, 256, 0, S3, nullptr, "convAB2.conv1", "convAB2.conv2"))) return rc;
   } else {
     if ((rc = conv(LAB2_1, c->ab, 256, 0, nullptr, 0, 0, c->ab_t, 256, 0, S3, 1, 0, "convAB2.conv1"))) return rc;
@@ -631,7 +672,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
     TailArgs tl{W + L.fc_w, W + L.fc_b, c->logits, c->fcpart, trans, rot, poseA, poseB, c->tn, c->rn};
     if ((rc = block(LH2_1, LH2_2, c->head, c->head_t, 1024, 512, S4, &tl, "trans|rot conv2.conv1",
                     "trans|rot conv2.conv2 + avgpool+fc+tanh+pose"))) return rc;
-    c->head_final = c->head;
+    c->head_final = fast ? c->head_f : c->head;
   } else {
     if ((rc = conv(LH2_1, c->head, 1024, 512, nullptr, 0, 0, c->head_t, 1024, 512, S4, 1, 0, "trans|rot conv2.conv1"))) return rc;
     float* head_out = fast ? c->head_f : c->head;

@@ -234,13 +234,16 @@ hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h,
 // rows x [cout][32] layout of the 3x3 panels (row_words = 32, rows = chunks x 9 taps, hi at +0, lo at +32 halves), or the
 // stem's [64][204] (one "row" of 200 used words per cout, 16-byte entries 4 hi | 4 lo).  weights.cpp: split_blob_host is the
 // host statement of the same arithmetic (checked bit for bit in tests/test_gpu_parity.py).
+// wino != 0: Winograd planes U [chunk][nf = wino][cout][32], one workgroup per (frequency f = blockIdx.y, cout): its rows are the
+// chunks only (stride nf cout 32), so that every frequency gets its own scale (the planes differ by up to ~2 orders of magnitude)
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, _Float16* __restrict__ ws,
-                                                             float* __restrict__ sc, int rows, int cout, int stem) {
+                                                             float* __restrict__ sc, int rows, int cout, int stem, int wino) {
   __shared__ float red[256];
   const int o = blockIdx.x, t = threadIdx.x;
   const int per_row = stem ? 200 : 32;
-  const size_t row_stride = stem ? 0 : (size_t)cout * 32;           // words between consecutive rows of one cout
-  const size_t base = stem ? (size_t)o * 204 : (size_t)o * 32;
+  const size_t row_stride = stem ? 0 : wino ? (size_t)wino * cout * 32 : (size_t)cout * 32;   // words between rows of one cout
+  const size_t base = stem ? (size_t)o * 204 : wino ? ((size_t)blockIdx.y * cout + o) * 32 : (size_t)o * 32;
+  if (wino) sc += (size_t)blockIdx.y * cout;
   float mx = 0.f;
   for (int i = t; i < rows * per_row; i += 256) {
     const int r = i / per_row, ci = i - r * per_row;
@@ -277,11 +280,17 @@ hipError_t launch_split_weights(const float* blob, const BlobLayout& L, float* s
       const size_t gw = conv3_words(spec[id].cin, spec[id].cout) * g;
       hipLaunchKernelGGL(split_weights_kernel, dim3(spec[id].cout), dim3(256), 0, st, blob + L.conv_w[id] + gw,
                          reinterpret_cast<_Float16*>(split + S.conv_ws[id] + gw), split + S.conv_sc[id] + (size_t)spec[id].cout * g,
-                         spec[id].cin / 32 * 9, spec[id].cout, 0);
+                         spec[id].cin / 32 * 9, spec[id].cout, 0, 0);
     }
   for (int br = 0; br < 2; ++br)
     hipLaunchKernelGGL(split_weights_kernel, dim3(64), dim3(256), 0, st, blob + L.stem_w + (size_t)br * 64 * 204,
-                       reinterpret_cast<_Float16*>(split + S.stem_ws + (size_t)br * 64 * 204), split + S.stem_sc + br * 64, 1, 64, 1);
+                       reinterpret_cast<_Float16*>(split + S.stem_ws + (size_t)br * 64 * 204), split + S.stem_sc + br * 64, 1, 64, 1, 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_split_wino_u(const float* U, float* Us, float* scale, int cin, int cout, int nf, hipStream_t st) {
+  hipLaunchKernelGGL(split_weights_kernel, dim3(cout, nf), dim3(256), 0, st, U, reinterpret_cast<_Float16*>(Us), scale, cin / 32, cout,
+                     0, nf);
   return hipGetLastError();
 }
 

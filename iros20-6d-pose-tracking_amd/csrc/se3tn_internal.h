@@ -172,6 +172,11 @@ struct WinoArgs {
   int C, Cout, groups;
   int in_gs, res_gs, out_gs, bias_gs;
   long long u_gs;     // floats per group of U
+  // f16x3 mode of the fused F(4x4) blocks (split != 0): in / res / out are split-row tensors, V is written as split rows, U points
+  // at the split planes and uscale[g][f][Cout] holds their exact power-of-two scales (undone in the GEMM epilogue, M is float32)
+  int split;
+  const float* uscale;
+  int* overflow;
 };
 
 // outputs of the fused out-transform + avg-pool + FC + tanh (wino_tail_kernel)
@@ -215,6 +220,8 @@ struct PerDeviceOnce {
 // launchers (defined in the .hip files)
 // f16x3 split panels + per-cout scales of every conv / both stems from the bound float32 blob (kernels_misc.hip)
 hipError_t launch_split_weights(const float* blob, const BlobLayout& L, float* split, const SplitLayout& S, hipStream_t st);
+// split rows + per-(frequency, cout) scales of one group's Winograd planes U [chunk][nf][cout][32] (f16x3 Winograd blocks)
+hipError_t launch_split_wino_u(const float* U, float* Us, float* scale, int cin, int cout, int nf, hipStream_t st);
 // NCHW [n,4,176,176] (nchw != 0) or plain NHWC [n,176,176,4] -> interior of the padded [n,182,182,4]
 hipError_t launch_to_padded_input(const float* in, float* out, int n, int nchw, int split, int* overflow,
                                   hipStream_t st);
@@ -234,7 +241,7 @@ hipError_t launch_wino_weights(const float* packed, float* U, int cin, int cout,
 hipError_t launch_wino_conv(const WinoArgs& a, int epi, hipStream_t st);
 // a whole residual block on the Winograd F(4x4) path with the fused mid / tail transforms (wino_mfma.hip);
 // mark_after_mid: optional profiling hook called between conv1 and conv2 (returns non-zero on error)
-hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* bias2, float* out2, int keep_mid,
+hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* uscale2, const float* bias2, float* out2, int keep_mid,
                              float* keep_out2, const TailArgs* tl, hipStream_t st, int mark_after_mid(void*), void* mark_ctx);
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,

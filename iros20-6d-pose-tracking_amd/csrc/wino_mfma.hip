@@ -90,6 +90,34 @@ __device__ __forceinline__ void axpy(float& acc, float c, float x, bool& first) 
   first = false;
 }
 
+// ---- f16x3 mode (SP != 0): activations / V as split rows (mfma_common.h), VEC consecutive channels c..c+VEC-1 --------
+// element (row, c) of a tensor with `ld` floats per row: hi halves at byte (row ld) 4 + (c >> 5) 128 + (c & 31) 2, lo 64 B on
+template <int VEC>
+__device__ __forceinline__ void load_split_vec(const float* base, size_t row, int ld, int c, float (&o)[VEC]) {
+  const unsigned char* p_ = reinterpret_cast<const unsigned char*>(base) + split_byte_off(row, ld, c);
+  typedef _Float16 hv __attribute__((ext_vector_type(VEC)));
+  const hv h = *reinterpret_cast<const hv*>(p_);
+  const hv l = *reinterpret_cast<const hv*>(p_ + 64);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) o[e] = (float)h[e] + (float)l[e];
+}
+template <int VEC>
+__device__ __forceinline__ bool store_split_vec(float* base, size_t row, int ld, int c, const float (&v)[VEC]) {
+  unsigned char* p_ = reinterpret_cast<unsigned char*>(base) + split_byte_off(row, ld, c);
+  typedef _Float16 hv __attribute__((ext_vector_type(VEC)));
+  hv h, l;
+  bool bad = false;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    h[e] = (_Float16)v[e];
+    l[e] = (_Float16)(v[e] - (float)h[e]);
+    bad |= !(fabsf(v[e]) <= 65000.f);
+  }
+  *reinterpret_cast<hv*>(p_) = h;
+  *reinterpret_cast<hv*>(p_ + 64) = l;
+  return bad;
+}
+
 // decode a flat thread index into (tile, vector of channels) and the tile into (image, ty, tx)
 struct TileId { int t, cv, n, ty, tx; };
 __device__ __forceinline__ TileId tile_of(int idx, int cvn, int th, int tw) {
@@ -103,7 +131,7 @@ __device__ __forceinline__ TileId tile_of(int idx, int cvn, int th, int tw) {
 }
 
 // one thread: (group, tile t, VEC channels)
-template <int M, int VEC>
+template <int M, int VEC, int SP = 0>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoArgs a) {
   constexpr int N = M + 2;
   typedef typename VecT<VEC>::type vec;
@@ -113,7 +141,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoArgs a) {
   const int g = blockIdx.y;
   const TileId id = tile_of(idx, cvn, a.th, a.tw);
   const int Hp = a.H + 2, Wp = a.W + 2;
-  const float* __restrict__ src = a.in + (size_t)g * a.in_gs + id.cv * VEC;
+  const float* __restrict__ src = a.in + (size_t)g * a.in_gs + (SP ? 0 : id.cv * VEC);
   // padded rows M ty .. M ty + M + 1 = input rows M ty - 1 .. M ty + M; windows of the last tile row /
   // column may reach past the border: those entries only feed dropped outputs
   float d[N][N][VEC];
@@ -122,6 +150,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoArgs a) {
 #pragma unroll
     for (int s = 0; s < N; ++s) {
       const int Y = M * id.ty + r, X = M * id.tx + s;
+      if (SP) {
+        if (Y < Hp && X < Wp) load_split_vec<VEC>(src, (size_t)((id.n * Hp + Y) * Wp + X), a.in_ld, id.cv * VEC, d[r][s]);
+        else for (int e = 0; e < VEC; ++e) d[r][s][e] = 0.f;
+        continue;
+      }
       vec v;
       if (Y < Hp && X < Wp) v = *reinterpret_cast<const vec*>(src + (size_t)((id.n * Hp + Y) * Wp + X) * a.in_ld);
       else __builtin_memset(&v, 0, sizeof(v));
@@ -140,8 +173,9 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoArgs a) {
         for (int r = 0; r < N; ++r) axpy(acc, wino_bt<M>(i, r), d[r][s][e], first);
         bt[i][s][e] = acc;
       }
-  float* __restrict__ dst = a.V + ((size_t)g * a.nf * a.T + id.t) * a.C + id.cv * VEC;
+  float* __restrict__ dst = a.V + ((size_t)g * a.nf * a.T + id.t) * a.C + (SP ? 0 : id.cv * VEC);
   const size_t fs = (size_t)a.T * a.C;  // floats per frequency plane
+  bool bad = false;
 #pragma unroll
   for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -155,14 +189,19 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoArgs a) {
         for (int s = 0; s < N; ++s) axpy(acc, wino_bt<M>(j, s), bt[i][s][e], first);
         o[e] = acc;
       }
+      if (SP) {   // V plane f as split rows of C floats: the GEMM's f16 hi | lo operand
+        bad |= store_split_vec<VEC>(dst + (size_t)(N * i + j) * fs, 0, a.C, id.cv * VEC, o);
+        continue;
+      }
       vec v;
       __builtin_memcpy(&v, o, sizeof(v));
       *reinterpret_cast<vec*>(dst + (size_t)(N * i + j) * fs) = v;
     }
+  if (SP && bad) atomicOr(a.overflow, 1);
 }
 
 // one thread: (group, tile t, VEC couts)
-template <int M, int VEC, int EPI>
+template <int M, int VEC, int EPI, int SP = 0>
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoArgs a) {
   constexpr int N = M + 2;
   typedef typename VecT<VEC>::type vec;
@@ -199,8 +238,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoArgs a) {
     const vec v = *reinterpret_cast<const vec*>(a.bias + (size_t)g * a.bias_gs + id.cv * VEC);
     __builtin_memcpy(b, &v, sizeof(v));
   }
-  const float* __restrict__ res = (EPI == 1) ? a.res + (size_t)g * a.res_gs + id.cv * VEC : nullptr;
-  float* __restrict__ out = a.out + (size_t)g * a.out_gs + id.cv * VEC;
+  const float* __restrict__ res = (EPI == 1) ? a.res + (size_t)g * a.res_gs + (SP ? 0 : id.cv * VEC) : nullptr;
+  float* __restrict__ out = a.out + (size_t)g * a.out_gs + (SP ? 0 : id.cv * VEC);
+  bool bad = false;
 #pragma unroll
   for (int i = 0; i < M; ++i)
 #pragma unroll
@@ -210,8 +250,12 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoArgs a) {
       const size_t pix = (size_t)((id.n * Hp + oy + 1) * Wp + ox + 1);
       float r[VEC];
       if (EPI == 1) {
-        const vec v = *reinterpret_cast<const vec*>(res + pix * a.res_ld);
-        __builtin_memcpy(r, &v, sizeof(v));
+        if (SP) {
+          load_split_vec<VEC>(res, pix, a.res_ld, id.cv * VEC, r);
+        } else {
+          const vec v = *reinterpret_cast<const vec*>(res + pix * a.res_ld);
+          __builtin_memcpy(r, &v, sizeof(v));
+        }
       }
       float o[VEC];
 #pragma unroll
@@ -224,10 +268,15 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoArgs a) {
         if (EPI == 1) acc += r[e];
         o[e] = fmaxf(acc, 0.f);
       }
+      if (SP) {
+        bad |= store_split_vec<VEC>(out, pix, a.out_ld, id.cv * VEC, o);
+        continue;
+      }
       vec v;
       __builtin_memcpy(&v, o, sizeof(v));
       *reinterpret_cast<vec*>(out + pix * a.out_ld) = v;
     }
+  if (SP && bad) atomicOr(a.overflow, 1);
 }
 
 // packed [chunk][9][cout][32] -> U [chunk][(M+2)^2][cout][32], one thread per (chunk, cout, k)
@@ -263,7 +312,7 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 // (one barrier per chunk), raw accumulators stored.  Workgroup id -> (cout panel, row tile, b) with
 // panel = id % panels: like the direct kernels an XCD (id % 8) only touches its own weight panel of b.
 // =================================================================================================
-template <int CIN, int WM, int WN, int PT, int CT>
+template <int CIN, int WM, int WN, int PT, int CT, int MM = MM_F32>
 __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
   constexpr int BM = WM * PT * 32, BN = WN * CT * 32;
   constexpr int NCH = CIN / 32;
@@ -355,10 +404,14 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
 #define FOG(G) ((G) == 0 ? fo0 : (G) == 1 ? fo1 : (G) == 2 ? fo2 : fo3)
 #define PXF(G) *reinterpret_cast<const float4*>(pP + i * 1024 + FOG(G))
 #define WTF(G) *reinterpret_cast<const float4*>(pW + j * 1024 + FOG(G))
-    SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
-    SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
-    SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
-    SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
+    if (MM == MM_F16X3) {   // V and U are split rows (f16 hi | lo): hi*hi + hi*lo + lo*hi on the f16 matrix cores
+      SE3TN_MMA_SPLIT(PT, CT, PXF, WTF)
+    } else {
+      SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
+      SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
+      SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
+      SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
+    }
 #undef PXF
 #undef WTF
 #undef FOG
@@ -371,6 +424,8 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
 #endif
   // lane holds row l31 x couts {8 q + 4 hh + 0..3} of each 32 x 32 block
   float* __restrict__ Mb = a.Mw + (size_t)b * a.T * a.Cout;
+  // MM_F16X3: the accumulators carry U's exact per-(frequency, cout) power-of-two scale: undo it here, M stays float32
+  const float* __restrict__ wsc = (MM == MM_F16X3) ? a.uscale + ((size_t)g * a.nf + f) * a.Cout : nullptr;
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     const int m = m0 + (wm * PT + i) * 32 + l31;
@@ -380,13 +435,125 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = n0 + (wn * CT + j) * 32 + q * 8 + hh * 4;
-        *reinterpret_cast<float4*>(Mb + (size_t)m * a.Cout + c) =
-            make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        float4 v = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        if (MM == MM_F16X3) {
+          const float4 w = *reinterpret_cast<const float4*>(wsc + c);
+          v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
+        }
+        *reinterpret_cast<float4*>(Mb + (size_t)m * a.Cout + c) = v;
       }
   }
 #ifdef SE3TN_WG_TRACE
   if (tid == 0 && blockIdx.x < 4096) ::se3tn_wg_trace[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();   // stores issued
 #endif
+}
+
+// -------------------------------------------------------------------------------------------------
+// wino_gemm8_kernel: the same 96 x 128 tile, LDS image and DMA as wino_gemm_kernel<CIN, 1, 4, 3, 1>, but EIGHT waves per
+// workgroup: waves 0-3 and 4-7 take the two 16-channel halves of every 32-channel K-step (intra-workgroup split-K), and the
+// two half sums are added through LDS at the end of the tile (fixed order: low half + high half).  Why: a WG-level trace of
+// the 4-wave kernel (scripts/wg_trace.py, profiles/r03_wg_trace.txt) shows that with 6.75 tiles per CU a CU spends ~21 % of
+// the launch with ONE resident workgroup = one wave per SIMD, which cannot keep the matrix pipe busy on its own (no
+// second wave to issue under its ds_reads / barrier / DMA wait).  With 8 waves a lone workgroup still has two waves per
+// SIMD, and two co-resident workgroups have four.
+template <int CIN>
+__global__ __launch_bounds__(512, 2) void wino_gemm8_kernel(const WinoArgs a) {
+  constexpr int PT = 3, BM = 96, BN = 128;
+  constexpr int NCH = CIN / 32;
+  constexpr int BUF = (BM + BN) * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wid & 3, kh = wid >> 2;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  const int panels = a.Cout / BN, mtiles = (a.T + BM - 1) / BM;
+  const int nt = blockIdx.x % panels, rest = blockIdx.x / panels;
+  const int mt = rest % mtiles, b = rest / mtiles;
+  const int g = b / a.nf, f = b - g * a.nf;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const float* __restrict__ Vb = a.V + (size_t)b * a.T * CIN;
+  const float* __restrict__ Ub = a.U + (size_t)g * a.u_gs + ((size_t)f * a.Cout + n0) * 32;
+  const int mlast = a.T - 1;
+
+  // staging: thread t fills LDS slot (t & 7) of row (t >> 3) + 64 j with channel block (t & 7) ^ ((row >> 1) & 7);
+  // V rows 0..95: pass 0 all eight waves, pass 1 waves 0-3 (rows 64..95); U rows 0..127: two passes
+  const int r0 = tid >> 3;
+  const int c4 = (tid & 7) ^ ((r0 >> 1) & 7);
+  const unsigned pv0 = (unsigned)((min(m0 + r0, mlast) * CIN + c4 * 4) * 4);
+  const unsigned pv1 = (unsigned)((min(m0 + r0 + 64, mlast) * CIN + c4 * 4) * 4);
+  const unsigned wvoff = (unsigned)((r0 * 32 + c4 * 4) * 4);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+#define ISSUE_TILE8(CH, BUFI)                                                                        \
+  {                                                                                                  \
+    const float* pb_ = Vb + (CH) * 32;                                                               \
+    const unsigned lb_ = lds0 + (unsigned)(((BUFI) * BUF + wid * 256) * 4);                          \
+    glds16<0>(pb_, pv0, lb_);                                                                        \
+    if (wid < 4) glds16<0>(pb_, pv1, lb_ + 8192);                                                    \
+    const float* tb_ = Ub + (size_t)(CH) * a.nf * a.Cout * 32;                                       \
+    glds16<0>(tb_, wvoff, lb_ + BM * 128);                                                           \
+    glds16<0>(tb_ + 2048, wvoff, lb_ + BM * 128 + 8192);                                             \
+  }
+
+  const int X = (l31 >> 1) & 7;
+  const int lo = (hh ^ (X & 1)) * 4, xk = X >> 1;
+  // this wave's two 8-k groups of a K-step: 2 kh, 2 kh + 1
+  const int foA = (((2 * kh) ^ xk) << 3) + lo, foB = (((2 * kh + 1) ^ xk) << 3) + lo;
+
+  f32x16 acc[PT][1];
+#pragma unroll
+  for (int i = 0; i < PT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.f;
+
+  ISSUE_TILE8(0, 0)
+  wait_dma_and_barrier();
+
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < NCH) ISSUE_TILE8(ch + 1, buf ^ 1)
+    const float* pP = smem + buf * BUF + l31 * 32;
+    const float* pW = smem + buf * BUF + (BM + wn * 32 + l31) * 32;
+#define PXF8(FO) *reinterpret_cast<const float4*>(pP + i * 1024 + (FO))
+#define WTF8(FO) *reinterpret_cast<const float4*>(pW + j * 1024 + (FO))
+    SE3TN_MMA_GROUP(PT, 1, PXF8(foA), WTF8(foA))
+    SE3TN_MMA_GROUP(PT, 1, PXF8(foB), WTF8(foB))
+#undef PXF8
+#undef WTF8
+    if (ch + 1 < NCH) wait_dma_and_barrier();
+  }
+#undef ISSUE_TILE8
+
+  // the two K halves meet in LDS (the operand buffers are free after this barrier): float4 slots [wn][i][q][lane]
+  __syncthreads();
+  float4* xch = reinterpret_cast<float4*>(smem);
+  if (kh == 1) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        xch[((wn * PT + i) * 4 + q) * 64 + lane] =
+            make_float4(acc[i][0][4 * q + 0], acc[i][0][4 * q + 1], acc[i][0][4 * q + 2], acc[i][0][4 * q + 3]);
+  }
+  __syncthreads();
+  if (kh == 1) return;
+  // lane holds row l31 x couts {8 q + 4 hh + 0..3} of each 32 x 32 block
+  float* __restrict__ Mb = a.Mw + (size_t)b * a.T * a.Cout;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int m = m0 + i * 32 + l31;
+    if (m > mlast) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 h = xch[((wn * PT + i) * 4 + q) * 64 + lane];
+      const int c = n0 + wn * 32 + q * 8 + hh * 4;
+      *reinterpret_cast<float4*>(Mb + (size_t)m * a.Cout + c) =
+          make_float4(acc[i][0][4 * q + 0] + h.x, acc[i][0][4 * q + 1] + h.y, acc[i][0][4 * q + 2] + h.z, acc[i][0][4 * q + 3] + h.w);
+    }
+  }
 }
 
 
@@ -403,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
 //                     one head, the 11 x 11 x 512 activation is reduced in registers and never stored
 //                     (again unless asked for).  The float64 pose update follows in pose_update_kernel.
 // =================================================================================================
-template <int TH, int CS>
+template <int TH, int CS, int SP = 0>
 __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_mid_kernel(const WinoArgs a, float* __restrict__ keep) {
   constexpr int M = 4, N = 6, HP = 4 * TH + 2, NT = TH * TH, CP = CS / 2, ITEMS = NT * CP;
   extern __shared__ __attribute__((aligned(16))) float act[];  // [HP][HP][CS], padded coordinates
@@ -482,8 +649,9 @@ __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_mi
           bt[i][s][e] = acc;
         }
     }
-    float* __restrict__ dst = a.V + ((size_t)g * a.nf * a.T + t) * a.C + c0 + cp * 2;
+    float* __restrict__ dst = a.V + ((size_t)g * a.nf * a.T + t) * a.C + (SP ? 0 : c0 + cp * 2);
     const size_t fs = (size_t)a.T * a.C;
+    bool bad = false;
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -497,8 +665,10 @@ __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_mi
           for (int s = 0; s < N; ++s) axpy(acc, wino_bt<M>(j, s), bt[i][s][e], first);
           o[e] = acc;
         }
-        *reinterpret_cast<float2*>(dst + (size_t)(N * i + j) * fs) = make_float2(o[0], o[1]);
+        if (SP) bad |= store_split_vec<2>(dst + (size_t)(N * i + j) * fs, 0, a.C, c0 + cp * 2, o);
+        else *reinterpret_cast<float2*>(dst + (size_t)(N * i + j) * fs) = make_float2(o[0], o[1]);
       }
+    if (SP && bad) atomicOr(a.overflow, 1);
   }
 }
 
@@ -512,7 +682,7 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // same parallelism; the per-channel sums over the map are reduced through LDS in a fixed order, each workgroup
 // contributes the partial dot products of its CS channels with the head's three FC rows:
 // fcpart[n][head][slice][3].  fc_finish_kernel adds the slices (fixed order), the bias, applies tanh and the pose update.
-template <int TH, int CS>
+template <int TH, int CS, int SP = 0>
 __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_tail_kernel(const WinoArgs a, float* __restrict__ keep,
                                                                                          const float* __restrict__ fc_w,
                                                                                          float* __restrict__ fcpart) {
@@ -527,8 +697,8 @@ __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_ta
     const int ty = tile / TH, tx = tile - ty * TH;
     const size_t fs = (size_t)a.T * a.Cout;
     const float* __restrict__ src = a.Mw + ((size_t)g * a.nf * a.T + n * NT + tile) * a.Cout + c;
-    const float* __restrict__ res = a.res + (size_t)g * a.res_gs + c;
-    float* __restrict__ kp = keep ? keep + (size_t)g * a.out_gs + c : nullptr;
+    const float* __restrict__ res = a.res + (size_t)g * a.res_gs + (SP ? 0 : c);
+    float* __restrict__ kp = keep ? keep + (size_t)g * a.out_gs + c : nullptr;   // always float32 (f16x3 mode: head_f)
     const float2 b = *reinterpret_cast<const float2*>(a.bias + (size_t)g * a.bias_gs + c);
     float u[M][N][2];
 #pragma unroll
@@ -558,7 +728,14 @@ __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_ta
         const int oy = M * ty + i, ox = M * tx + j;
         if (oy >= a.H || ox >= a.W) continue;
         const size_t pix = (size_t)((n * Hp + oy + 1) * Wp + ox + 1);
-        const float2 r = *reinterpret_cast<const float2*>(res + pix * a.res_ld);
+        float2 r;
+        if (SP) {
+          float rr[2];
+          load_split_vec<2>(res, pix, a.res_ld, c, rr);
+          r = make_float2(rr[0], rr[1]);
+        } else {
+          r = *reinterpret_cast<const float2*>(res + pix * a.res_ld);
+        }
         float o[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -631,10 +808,10 @@ hipError_t launch_wino_weights(const float* packed, float* U, int cin, int cout,
   return hipGetLastError();
 }
 
-template <int CIN, int WM, int WN, int PT, int CT>
+template <int CIN, int WM, int WN, int PT, int CT, int MM = MM_F32>
 static hipError_t launch_gemm(const WinoArgs& a, hipStream_t st) {
   static PerDeviceOnce attr;
-  auto kern = wino_gemm_kernel<CIN, WM, WN, PT, CT>;
+  auto kern = wino_gemm_kernel<CIN, WM, WN, PT, CT, MM>;
   constexpr int BM = WM * PT * 32, BN = WN * CT * 32;
   const size_t lds = 2 * (BM + BN) * 32 * sizeof(float);
   bool* done = attr.current();
@@ -649,12 +826,33 @@ static hipError_t launch_gemm(const WinoArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <int CIN>
+static hipError_t launch_gemm8(const WinoArgs& a, hipStream_t st) {
+  static PerDeviceOnce attr;
+  auto kern = wino_gemm8_kernel<CIN>;
+  const size_t lds = 2 * (96 + 128) * 32 * sizeof(float);
+  bool* done = attr.current();
+  if (!done || !*done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (done) *done = true;
+  }
+  const int grid = (a.Cout / 128) * ((a.T + 95) / 96) * a.groups * a.nf;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+  return hipGetLastError();
+}
+
+#ifndef SE3TN_WINO_GEMM8
+#define SE3TN_WINO_GEMM8 0   // 1: 96-row tiles run as 8-wave workgroups with intra-workgroup split-K (wino_gemm8_kernel)
+#endif
 // 128- or 96-row tiles: whichever leaves the shorter per-CU queue (in 32 x 32 x K blocks) on 256 CUs
 template <int CIN>
 static hipError_t launch_gemm_auto(const WinoArgs& a, hipStream_t st) {
   const long long per_b = (long long)(a.Cout / 128) * a.groups * a.nf;
   const long long q128 = ((((a.T + 127) / 128) * per_b + 255) / 256) * 16;
   const long long q96 = ((((a.T + 95) / 96) * per_b + 255) / 256) * 12;
+  if (a.split) return q96 < q128 ? launch_gemm<CIN, 1, 4, 3, 1, MM_F16X3>(a, st) : launch_gemm<CIN, 2, 2, 2, 2, MM_F16X3>(a, st);
+  if (SE3TN_WINO_GEMM8 && q96 < q128) return launch_gemm8<CIN>(a, st);
   return q96 < q128 ? launch_gemm<CIN, 1, 4, 3, 1>(a, st) : launch_gemm<CIN, 2, 2, 2, 2>(a, st);
 }
 
@@ -676,12 +874,12 @@ static hipError_t launch_transformed(const WinoArgs& a, int epi, hipStream_t st)
 // the out-transform with the residual epilogue or (tl != nullptr, the heads' last block) the fused
 // out-transform + avg-pool + FC + tanh.  c1 describes conv1 (in = block input, out = the intermediate activation
 // buffer, only written if keep_mid); conv2 reads the same V / Mw workspaces, residual = c1.in, output = out2.
-template <int TH, int CS>
+template <int TH, int CS, int SP = 0>
 static hipError_t launch_mid(const WinoArgs& a, float* keep, hipStream_t st) {
   constexpr int HP = 4 * TH + 2, THREADS = ((TH * TH * (CS / 2) + 63) / 64) * 64;
   constexpr size_t lds = (size_t)HP * HP * CS * sizeof(float);
   static PerDeviceOnce attr;
-  auto kern = wino_mid_kernel<TH, CS>;
+  auto kern = wino_mid_kernel<TH, CS, SP>;
   bool* done = attr.current();
   if (!done || !*done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -692,34 +890,39 @@ static hipError_t launch_mid(const WinoArgs& a, float* keep, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* bias2, float* out2, int keep_mid,
+hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* uscale2, const float* bias2, float* out2, int keep_mid,
                              float* keep_out2, const TailArgs* tl, hipStream_t st, int mark_after_mid(void*), void* mark_ctx) {
   if (c1.m != 4 || c1.nf != 36 || c1.C != c1.Cout || (c1.C != 256 && c1.C != 512)) return hipErrorInvalidValue;
   if (!((c1.th == 6 && c1.C == 256) || (c1.th == 3 && c1.C == 512)) || c1.tw != c1.th) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((wino_input_kernel<4, WINO4_VEC>), dim3((c1.T * (c1.C / WINO4_VEC) + 255) / 256, c1.groups), dim3(256), 0, st, c1);
+  const dim3 ig((c1.T * (c1.C / WINO4_VEC) + 255) / 256, c1.groups);
+  if (c1.split) hipLaunchKernelGGL((wino_input_kernel<4, WINO4_VEC, 1>), ig, dim3(256), 0, st, c1);
+  else hipLaunchKernelGGL((wino_input_kernel<4, WINO4_VEC>), ig, dim3(256), 0, st, c1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   e = c1.C == 256 ? launch_gemm_auto<256>(c1, st) : launch_gemm_auto<512>(c1, st);
   if (e != hipSuccess) return e;
-  e = c1.th == 6 ? launch_mid<6, WINO_MID_CS_AB>(c1, keep_mid ? c1.out : nullptr, st)
-                 : launch_mid<3, WINO_MID_CS_H>(c1, keep_mid ? c1.out : nullptr, st);
+  float* keep1 = keep_mid ? c1.out : nullptr;
+  if (c1.split) e = c1.th == 6 ? launch_mid<6, WINO_MID_CS_AB, 1>(c1, keep1, st) : launch_mid<3, WINO_MID_CS_H, 1>(c1, keep1, st);
+  else e = c1.th == 6 ? launch_mid<6, WINO_MID_CS_AB>(c1, keep1, st) : launch_mid<3, WINO_MID_CS_H>(c1, keep1, st);
   if (e != hipSuccess) return e;
   if (mark_after_mid && mark_after_mid(mark_ctx)) return hipErrorUnknown;
   WinoArgs c2 = c1;
-  c2.U = U2; c2.bias = bias2; c2.res = c1.in; c2.res_ld = c1.in_ld; c2.res_gs = c1.in_gs; c2.out = out2;
+  c2.U = U2; c2.uscale = uscale2; c2.bias = bias2; c2.res = c1.in; c2.res_ld = c1.in_ld; c2.res_gs = c1.in_gs; c2.out = out2;
   e = c1.C == 256 ? launch_gemm_auto<256>(c2, st) : launch_gemm_auto<512>(c2, st);
   if (e != hipSuccess) return e;
   if (tl) {
     if (c1.th != 3 || c1.groups != 2 || c1.Cout != 512) return hipErrorInvalidValue;
     constexpr int CS = 64, THREADS = ((9 * (CS / 2) + 63) / 64) * 64;
-    hipLaunchKernelGGL((wino_tail_kernel<3, CS>), dim3(c1.n, 512 / CS, 2), dim3(THREADS), 0, st, c2, keep_out2, tl->fc_w, tl->fcpart);
+    if (c1.split) hipLaunchKernelGGL((wino_tail_kernel<3, CS, 1>), dim3(c1.n, 512 / CS, 2), dim3(THREADS), 0, st, c2, keep_out2, tl->fc_w, tl->fcpart);
+    else hipLaunchKernelGGL((wino_tail_kernel<3, CS>), dim3(c1.n, 512 / CS, 2), dim3(THREADS), 0, st, c2, keep_out2, tl->fc_w, tl->fcpart);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fc_finish_kernel, dim3((c1.n + 9) / 10), dim3(64), 0, st, tl->fcpart, 512 / CS, *tl, tl->poseA, tl->poseB,
                        tl->tn, tl->rn, c1.n);
   } else {
     const dim3 og((c2.T * (c2.Cout / WINO4_VEC) + 255) / 256, c2.groups);
-    hipLaunchKernelGGL((wino_output_kernel<4, WINO4_VEC, 1>), og, dim3(256), 0, st, c2);
+    if (c1.split) hipLaunchKernelGGL((wino_output_kernel<4, WINO4_VEC, 1, 1>), og, dim3(256), 0, st, c2);
+    else hipLaunchKernelGGL((wino_output_kernel<4, WINO4_VEC, 1>), og, dim3(256), 0, st, c2);
   }
   return hipGetLastError();
 }
