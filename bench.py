@@ -462,7 +462,8 @@ def main():
         c2 = float(np.mean([eng.profile_read(s_)[0] for s_ in range(sl)]))
         eng.profile_enable(0)
         other = {"precision": "f16x3", "what": "every 3x3 conv as hi*hi+hi*lo+lo*hi on v_mfma_f32_32x32x16_f16 with split-row "
-                 "(f16 hi|lo) operands, f32 accumulate",
+                 "(f16 hi|lo) operands, f32 accumulate; the 512-channel head block as fused Winograd F(4x4) passes on the same "
+                 "split operands (the 256-channel block stays direct: its batched GEMMs are bandwidth-bound at the f16 rate)",
                  "value": round(world * nb * steps_timed / dt2, 1), "unit": "pairs/s", "ms_per_step": round(dt2 / steps_timed * 1e3, 4),
                  "steps_timed": steps_timed, "conv_ms_per_step": round(c2, 4),
                  "conv_tflops_f32_equivalent": round(CONV3_FLOP_PER_PAIR * nb / (c2 * 1e-3) / 1e12, 1),
