@@ -800,6 +800,26 @@ def physical_cores():
     return [c for _, c in sorted(out)]
 
 
+def cpu_quota_cores():
+    """CPU time this container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None if unlimited.  The GPU boxes of this
+    pool expose 256 logical CPUs but run under a 16-core quota: more busy threads than that are CFS-throttled, which is what made
+    the all-cores figures of rounds 1 / 2 collapse (256 threads: ~1 pair/s)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def _cpu_worker(cpus, threads, seconds, chunk, start, q):
     """One pinned oracle process of the cpu_baseline: the WHOLE per-pair path (crop_bbox + processData on numpy, the network
     on torch-CPU in forwards of `chunk` pairs, processPredict), for `seconds` after a common start."""
@@ -878,9 +898,10 @@ def cpu_multiprocess_rate(procs, threads, seconds, chunk, cores):
 def cpu_baseline(O, sd, nb, inputs=None):
     """The CPU oracle (torch-CPU fp32 restatement of the reference network + numpy pre/post) timed on this box's host cores
     on a bounded sample (~40 s).  `value` = the BEST whole-path configuration measured in THIS run (every configuration is
-    timed once, for the same duration, and the reported figure is that measurement -- never a sweep winner re-timed):
-    single process with 16 / 32 / 64 threads, and K pinned processes x T threads on disjoint physical cores (a single oneDNN
-    process cannot use a 2 x 64-core box: 256 threads -> ~1 pair/s).  Batch 1 (what the reference's live tracker runs) beside it."""
+    timed once, for the same duration, and the reported figure is that measurement -- never a sweep winner re-timed).
+    The usable cores are min(physical cores, the container's cgroup CPU quota): configurations are one process with Q and Q/2
+    threads, K pinned processes x T threads with K T = Q on disjoint physical cores, and ONE over-quota configuration (2 Q
+    threads) that documents the throttling.  Batch 1 (what the reference's live tracker runs) beside it."""
     import numpy as np
     import torch
     from oracle import fixtures as Fx
@@ -888,6 +909,8 @@ def cpu_baseline(O, sd, nb, inputs=None):
     model, sockets = cpu_model()
     cores = physical_cores()
     P = len(cores)
+    quota = cpu_quota_cores()
+    Q = max(1, min(P, int(quota) if quota else P))   # cores this container can keep busy
     A, B = inputs if inputs is not None else Fx.net_inputs(3, nb)
     SECONDS, CHUNK = 4.0, 16
     mean, std = Fx.mean_std(0)
@@ -902,7 +925,7 @@ def cpu_baseline(O, sd, nb, inputs=None):
     configs = {}
     # single process: network on the timed batch's own pairs in forwards of 16, + the measured numpy pre/post per pair
     old_aff = os.sched_getaffinity(0)
-    for th in sorted({t for t in (16, 32, 64) if t <= P} or {P}):
+    for th in sorted({t for t in (Q, max(1, Q // 2), 2 * Q) if t <= P} or {P}):
         try:
             os.sched_setaffinity(0, set(cores[:th]))
         except OSError:
@@ -918,7 +941,7 @@ def cpu_baseline(O, sd, nb, inputs=None):
                                   "network_only": round(net, 2)}
     # batch 1: best of a small thread sweep, 10 forwards each
     b1 = {}
-    for th in sorted({t for t in (8, 16, 32) if t <= P} or {P}):
+    for th in sorted({t for t in (max(1, Q // 2), Q) if t <= P} or {P}):
         try:
             os.sched_setaffinity(0, set(cores[:th]))
         except OSError:
@@ -935,9 +958,9 @@ def cpu_baseline(O, sd, nb, inputs=None):
         pass
     # K pinned processes x T threads over the physical cores (whole path inside every worker)
     errors = {}
-    for th in (16, 8, 32):
-        k = P // th
-        if k < 2:
+    for k in (2, 4):
+        th = Q // k
+        if th < 2:
             continue
         rate, err = cpu_multiprocess_rate(k, th, SECONDS, CHUNK, cores)
         if rate is None:
@@ -951,14 +974,15 @@ def cpu_baseline(O, sd, nb, inputs=None):
     out = {"value": configs[best]["value"], "unit": "pairs/s", "cores": configs[best]["processes"] * configs[best]["threads"],
            "kind": "port", "configuration": best + " (processes x threads, pinned to disjoint physical cores)",
            "cpu_model": model, "sockets": sockets, "logical_cpus": ncpu, "physical_cores": P,
+           "cgroup_cpu_quota_cores": quota, "usable_cores": Q,
            "configurations_pairs_per_s": configs,
            "single_process_best": {"configuration": single, "value": configs[single]["value"], "cores": configs[single]["threads"]},
            "batch1": {"value": round(1.0 / (1.0 / b1[b1_best] + pp_s_per_pair), 2), "cores": b1_best,
                       "network_only_by_threads": b1, "unit": "pairs/s"},
            "prepost_ms_per_pair": round(pp_s_per_pair * 1e3, 3),
            "sample": "oracle (torch-CPU fp32 port of the reference network + numpy crop / normalise / pose update; %s x%d sockets, "
-                     "%d physical cores): every configuration timed once for %.0f s in forwards of %d pairs; value = the best of them"
-                     % (model, sockets, P, SECONDS, CHUNK)}
+                     "%d physical cores, cgroup CPU quota %s cores): every configuration timed once for %.0f s in forwards of %d pairs; "
+                     "value = the best of them" % (model, sockets, P, ("%.0f" % quota) if quota else "none", SECONDS, CHUNK)}
     if errors:
         out["configurations_failed"] = errors
     return out
