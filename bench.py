@@ -743,6 +743,11 @@ def pmc_traffic(nb, wino_on):
         if base in wino_calls:
             if not wino_on:
                 continue
+            if "<" in k:   # the f16x3 instantiations (last template argument SP / MM = 1) belong to the alt_precision leg
+                targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
+                nargs = {"wino_input_kernel": 3, "wino_output_kernel": 4, "wino_mid_kernel": 3, "wino_tail_kernel": 3, "wino_gemm_kernel": 6}
+                if len(targs) == nargs.get(base, -1) and targs[-1] == "1":
+                    continue
             total += wino_calls[base] * (2.0 * v["FETCH_SIZE"] + d["write"][k]["WRITE_SIZE"]) * 1024.0
             continue
         if not k.startswith("conv3x3") or "<" not in k:
