@@ -39,6 +39,9 @@
 #ifndef SE3TN_PERSISTENT_SLAB
 #define SE3TN_PERSISTENT_SLAB 1  // 0: one workgroup per tile (A/B timing only)
 #endif
+#ifndef SE3TN_SLAB_RELAXED
+#define SE3TN_SLAB_RELAXED 0     // 1: the slab piece of the NEXT chunk stays in flight across the K-step barriers (counted vmcnt)
+#endif
 
 namespace se3tn {
 
@@ -231,10 +234,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_slab_kernel(const ConvArgs a) 
         } else if (more) {
           WEIGHT_TILE(0, 0, wb ^ 1)
         }
+        // (the weight tile is issued BEFORE the slab piece: a counted wait that leaves one operation in flight leaves the
+        // slab piece, which nobody reads before the next chunk)
+        bool piece_in_flight = false;
         if (ch + 1 < NCH) {
           SLAB_PIECE(lo, npieces, ch + 1, sb ^ 1, tap)
+          piece_in_flight = (wid + 8 * tap) < npieces;
         } else if (more) {
           SLAB_PIECE(nlo, nnp, 0, 0, tap)
+          piece_in_flight = (wid + 8 * tap) < nnp;
         }
 
         const int r = tap / 3, s = tap - r * 3;
@@ -261,7 +269,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_slab_kernel(const ConvArgs a) 
         }
 #undef PXF
 #undef WTF
-        if (kt + 1 < NCH * 9 || more) wait_dma_and_barrier();
+        if (kt + 1 < NCH * 9 || more) {
+          if (SE3TN_SLAB_RELAXED && MM == MM_F32 && tap < 8) {
+            // next K-step reads only the weight tile just fetched: wait for it (operations retire in order), let this wave's
+            // slab piece fly on; the whole slab is drained (vmcnt(0)) at the chunk's last K-step, before anybody reads it
+            if (piece_in_flight) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+          } else {
+            wait_dma_and_barrier();
+          }
+        }
       }
     }
     store_tiles<PT, CT, EPI, MM, OUTF, RESF>(a, g, acc, opix, ok, n0 + wn * CT * 32, hh, PREFETCH_RES ? rpre : nullptr);
