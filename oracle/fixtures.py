@@ -145,3 +145,18 @@ def icosphere(subdiv=2, radius=0.05, seed=0):
     rng = np.random.default_rng(seed)
     return dict(vertices=(v * radius).astype(np.float32), faces=np.array(f, np.int32),
                 colors=rng.integers(40, 256, (len(v), 3)).astype(np.float64), normals=v.copy())
+
+
+def textured_sphere(subdiv=2, radius=0.05, tex_hw=(64, 128)):
+    """icosphere with spherical texture coordinates and a synthetic RGB texture (ramps + checker + white speckles): the mesh of the
+    pyrender-route tests (tests/test_renderer.py, tests/test_gl_swiftshader.py).  Returns dict(vertices f64, faces, uv, texture u8, kd)."""
+    m = icosphere(subdiv, radius, 3)
+    v = m["vertices"].astype(np.float64)
+    n = v / np.linalg.norm(v, axis=1, keepdims=True)
+    uv = np.stack([0.5 + np.arctan2(n[:, 1], n[:, 0]) / (2 * np.pi), 0.5 + np.arcsin(np.clip(n[:, 2], -1, 1)) / np.pi], 1)
+    rng = np.random.default_rng(9)
+    th, tw = tex_hw
+    yy, xx = np.mgrid[0:th, 0:tw]
+    tex = np.stack([(xx * 255 // (tw - 1)), (yy * 255 // (th - 1)), ((xx // 8 + yy // 8) % 2) * 200 + 30], -1).astype(np.uint8)
+    tex[rng.random((th, tw)) < 0.05] = (255, 255, 255)
+    return dict(vertices=v, faces=m["faces"], uv=uv, texture=tex, kd=np.array([0.9, 1.0, 0.8]), colors=m["colors"])

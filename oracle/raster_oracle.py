@@ -4,10 +4,11 @@ Written as the literal GL pipeline -- the reference's own matrices (update_cam_m
 NDC -> window transform, pixel-centre sampling with the top-left rule, LESS depth test, no face culling
 (set_cull_face only selects glCullFace; GL_CULL_FACE is never enabled), perspective-correct varyings, the
 fragment shader (:54-76), bottom-up read-back and the depth linearisation (:160-169).
-PARITY UNPINNED against an OpenGL implementation (none is available offline).  What IS pinned, independently of this
-file: the geometry -- projection, y-flip, window scaling, row order, depth linearisation -- against the analytic
-ray-sphere intersection (tests/test_renderer.py: test_oracle_vs_analytic_sphere, and the same check on the HIP kernels);
-the shading and GL's fill rules are not."""
+Pinned (round 3) against a real OpenGL implementation: tests/golden/gl_swiftshader.npz holds what the UNMODIFIED reference class
+VispyRenderer renders on SwiftShader's OpenGL ES 3.0 (oracle/swiftshader_gl.py, oracle/make_gl_golden.py); this file agrees with
+it on coverage up to a handful of silhouette pixels (SwiftShader snaps vertices to 1/16 pixel), depth <= 1 mm, interior colours
+<= 2-3 / 255 (tests/test_gl_swiftshader.py).  The geometry is additionally pinned against the analytic ray-sphere intersection
+(tests/test_renderer.py: test_oracle_vs_analytic_sphere, and the same check on the HIP kernels)."""
 import numpy as np
 
 
@@ -100,7 +101,8 @@ from .fixtures import icosphere  # noqa: E402,F401  (the test mesh lives with th
 # (predict.py:161-164, :209-213).  Restated as the GL pipeline pyrender sets up: IntrinsicsCamera projection at the
 # camera's W x H, object pose = cvcam_in_glcam . ob_in_cvcam, a scene lit by ambient light [1,1,1] only (fragment
 # colour = base colour = Kd x texture | vertex colour), colour rows flipped to top-down on read-back, depth buffer
-# linearised to metres.  PARITY UNPINNED (no GL / pyrender offline; texture filtering is driver-defined).
+# linearised to metres.  GL's sampling / fill rules pinned against SwiftShader (tests/test_gl_swiftshader.py); pyrender's own scene set-up
+# (not installable offline) remains this file's reading.
 # ------------------------------------------------------------------------------------------------------------------
 def mip_pyramid(tex):
     """RGB uint8 [h,w,3] -> list of levels, each the 2x2 box filter of the previous (rounded to nearest)."""

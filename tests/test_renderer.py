@@ -99,15 +99,8 @@ def test_tracker_with_builtin_renderer(se3, tmp_path):
 def _textured_sphere(tmp_path, subdiv=2, radius=0.05, tex_hw=(64, 128)):
     """icosphere with spherical texture coordinates, written as .obj + .mtl + .png; returns (paths, mesh dict)."""
     from PIL import Image
-    m = R.icosphere(subdiv, radius, 3)
-    v = m["vertices"].astype(np.float64)
-    n = v / np.linalg.norm(v, axis=1, keepdims=True)
-    uv = np.stack([0.5 + np.arctan2(n[:, 1], n[:, 0]) / (2 * np.pi), 0.5 + np.arcsin(np.clip(n[:, 2], -1, 1)) / np.pi], 1)
-    rng = np.random.default_rng(9)
-    th, tw = tex_hw
-    yy, xx = np.mgrid[0:th, 0:tw]
-    tex = np.stack([(xx * 255 // (tw - 1)), (yy * 255 // (th - 1)), ((xx // 8 + yy // 8) % 2) * 200 + 30], -1).astype(np.uint8)
-    tex[rng.random((th, tw)) < 0.05] = (255, 255, 255)
+    ms = Fx.textured_sphere(subdiv, radius, tex_hw)
+    m, v, uv, tex = ms, ms["vertices"], ms["uv"], ms["texture"]
     Image.fromarray(tex).save(tmp_path / "tex.png")
     (tmp_path / "obj.mtl").write_text("newmtl m0\nKa 0.2 0.2 0.2\nKd 0.9 1.0 0.8\nmap_Kd tex.png\n")
     with open(tmp_path / "obj.obj", "w") as f:
