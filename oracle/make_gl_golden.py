@@ -5,8 +5,8 @@ Tracker.render_window drives it (predict.py:193-208), and stores the images as t
 
     python -m oracle.make_gl_golden [out_dir]
 
-Cases = tests/test_renderer.py::test_hip_rasteriser_vs_oracle's (mesh seed, subdivisions, translation) + two more poses; every
-case with the depth attachment vispy creates (GL_DEPTH_COMPONENT16) and, for information, with a 32-bit float one (SwiftShader does not return a 24-bit buffer correctly through GL_NV_read_depth)."""
+Cases = tests/test_renderer.py::test_hip_rasteriser_vs_oracle's (mesh seed, subdivisions, translation) + two more poses; depth
+attachment: GL_DEPTH_COMPONENT32F (see oracle/swiftshader_gl.py: DEPTH_FORMAT)."""
 import importlib
 import os
 import sys

@@ -259,7 +259,11 @@ class _Texture2D:
         gl.check("Texture2D")
 
 
-DEPTH_FORMAT = {"bits": 16}   # vispy attaches a format-less RenderBuffer as GL_DEPTH_COMPONENT16 (gloo/glir.py: GlirFrameBuffer._formats)
+# vispy attaches a format-less RenderBuffer as GL_DEPTH_COMPONENT16 (gloo/glir.py: GlirFrameBuffer._formats).  SwiftShader cannot read a
+# fixed-point depth buffer back correctly through GL_NV_read_depth (16 bit: the rows come back in its internal 2x2-quad order; 24 bit: 0 / 1
+# only), so the stand-in attaches GL_DEPTH_COMPONENT32F: identical visibility for the test scenes (front / back surfaces are centimetres
+# apart), read-back values within one 16-bit quantum (0.06-0.3 mm at 0.65-1.5 m) of what a 16-bit buffer would return.
+DEPTH_FORMAT = {"bits": 32}
 
 
 class _RenderBuffer:
@@ -326,21 +330,10 @@ def _glReadPixels(x, y, w, h, fmt, typ):
         gl.check("glReadPixels RGBA")
         return np.ascontiguousarray(buf[..., :3]).tobytes()
     if fmt == GL_DEPTH_COMPONENT and typ == GL_FLOAT:
-        # GL_NV_read_depth returns a fixed-point depth buffer in its own type only (UNSIGNED_SHORT for 16 bits, UNSIGNED_INT_24_8
-        # for 24); desktop GL's GL_FLOAT read-back of such a buffer is the pixel-transfer conversion d / (2^b - 1): done here
         assert "GL_NV_read_depth" in gl.extensions
-        bits = DEPTH_FORMAT["bits"]
-        if bits == 16:
-            raw = np.zeros((h, w), np.uint16)
-            gl.glReadPixels(x, y, w, h, GL_DEPTH_COMPONENT, 0x1403, raw.ctypes.data)           # GL_UNSIGNED_SHORT
-            buf = raw.astype(np.float32) / np.float32(65535.0)
-        elif bits == 24:
-            raw = np.zeros((h, w), np.uint32)
-            gl.glReadPixels(x, y, w, h, GL_DEPTH_COMPONENT, 0x84FA, raw.ctypes.data)           # GL_UNSIGNED_INT_24_8
-            buf = ((raw >> 8).astype(np.float64) / 16777215.0).astype(np.float32)
-        else:
-            buf = np.zeros((h, w), np.float32)
-            gl.glReadPixels(x, y, w, h, GL_DEPTH_COMPONENT, GL_FLOAT, buf.ctypes.data)
+        assert DEPTH_FORMAT["bits"] == 32, "only the float depth attachment reads back correctly on SwiftShader (see DEPTH_FORMAT)"
+        buf = np.zeros((h, w), np.float32)
+        gl.glReadPixels(x, y, w, h, GL_DEPTH_COMPONENT, GL_FLOAT, buf.ctypes.data)
         gl.check("glReadPixels DEPTH")
         return buf
     raise NotImplementedError((fmt, typ))
