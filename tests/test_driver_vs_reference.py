@@ -1,0 +1,71 @@
+"""The headless YCBInEOAT sequence driver against the reference's own driver.  tests/golden/driver_ycbineoat.npz = the result files
+of the UNMODIFIED `predict.predictSequenceYcbInEOAT()` (predict.py:578-626) run end to end in the build container
+(oracle/make_driver_golden.py: the reference's Tracker with the 30-degree normaliser, its renderer on a real GL, torch-CPU) on a
+synthetic video, plus the image A of every frame.  GPU: sequence.predict_sequence_ycbineoat with the drop-in Tracker on the same
+video (regenerated from the fixtures) writes the same files with the same poses."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fixtures as Fx
+from oracle import se3_oracle as O
+from oracle.make_driver_golden import N_FRAMES, VIDEO, make_video
+from oracle.make_predict_golden import HEAD_GAIN, MESH, OBJECT_WIDTH
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "driver_ycbineoat.npz"))
+
+
+def test_reference_driver_golden_facts(golden, tmp_path):
+    assert [str(f) for f in golden["files"]] == ["%07d.txt" % i for i in range(N_FRAMES)]      # frame 0 is tracked too; %07d.txt
+    video = make_video(str(tmp_path))
+    first = np.loadtxt(os.path.join(video, "annotated_poses", "0000000.txt"))
+    assert np.allclose(golden["poses_in"][0], first)                                            # initial pose = annotated_poses[0]
+    for i in range(1, N_FRAMES):                                                                # pose feedback, no re-initialisation
+        assert np.allclose(golden["poses_in"][i], golden["poses"][i - 1], atol=1e-12)
+    # the oracle's composition reproduces the reference driver's poses (30-degree rotation normaliser, predict.py:586)
+    from PIL import Image
+    sd = O.make_state_dict(0, head_gain=HEAD_GAIN)
+    mean, std = Fx.mean_std(0)
+    for i in range(N_FRAMES):
+        rgb = np.array(Image.open(os.path.join(video, "rgb", "%07d.png" % i)))[:, :, :3]
+        depth = np.array(Image.open(os.path.join(video, "depth_filled", "%07d.png" % i))).astype(np.uint16)
+        want, _ = O.on_track(sd, golden["poses_in"][i], rgb, depth, golden["rgbA"][i], golden["depthA"][i], Fx.K_YCB, OBJECT_WIDTH,
+                             mean, std, 0.03, 30 * np.pi / 180)
+        assert np.abs(want - golden["poses"][i]).max() < 1e-6, i
+
+
+@pytest.mark.gpu
+def test_dropin_driver_writes_what_the_reference_driver_writes(golden, tmp_path):
+    import se3tracknet_amd as se3
+    video = make_video(str(tmp_path))
+    sd = O.make_state_dict(0, head_gain=HEAD_GAIN)
+    mean, std = Fx.mean_std(0)
+    calls = [0]
+
+    class ReferenceImageA:
+        def render(self, ob2cam, K, window):
+            i = calls[0]; calls[0] += 1
+            assert np.abs(np.asarray(ob2cam) - golden["poses_in"][i]).max() < 1e-5       # the pose fed back is the reference's
+            return golden["rgbA"][i], golden["depthA"][i]
+    trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=OBJECT_WIDTH), mean, std, {"state_dict": sd}, renderer=ReferenceImageA(),
+                      trans_normalizer=0.03, rot_normalizer=30 * np.pi / 180)
+    out = str(tmp_path / "res" / VIDEO)
+    res = se3.sequence.predict_sequence_ycbineoat(trk, video, out)
+    assert sorted(os.listdir(out)) == [str(f) for f in golden["files"]]
+    worst = 0.0
+    for i, f in enumerate(golden["files"]):
+        worst = max(worst, float(np.abs(np.loadtxt(os.path.join(out, str(f))) - golden["poses"][i]).max()))
+    print("drop-in driver vs predict.predictSequenceYcbInEOAT result files: max |d pose| %.2e over %d frames" % (worst, len(golden["files"])))
+    assert worst < 1e-5 and res["frames"] == N_FRAMES
+    # the same video with the HIP rasteriser producing image A
+    hip = se3.Tracker(dict(Fx.DATASET_INFO, object_width=OBJECT_WIDTH), mean, std, {"state_dict": sd}, trans_normalizer=0.03,
+                      rot_normalizer=30 * np.pi / 180)
+    hip.renderer = se3.HipRenderer(hip.engine, Fx.icosphere(*MESH))
+    res2 = se3.sequence.predict_sequence_ycbineoat(hip, video, str(tmp_path / "res2" / VIDEO))
+    d = float(np.abs(res2["poses"] - golden["poses"]).max())
+    print("  with the HIP rasteriser's image A (errors compound over %d frames of feedback): %.2e" % (N_FRAMES, d))
+    assert d < 5e-2      # informational bound: ~1e-3 per frame from the silhouette pixels (tests/test_gl_swiftshader.py) x 30 deg, not contracted by a random-init net
