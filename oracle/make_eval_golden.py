@@ -47,8 +47,11 @@ def _open3d_stub():
 def load_reference_evaluators():
     ref_shims.install()
     sys.modules["open3d"] = _open3d_stub()
-    for m in ("matplotlib", "matplotlib.pyplot"):
-        sys.modules.setdefault(m, types.ModuleType(m))
+    try:
+        import matplotlib.pyplot  # noqa: F401  (eval_ycb imports pyplot at module level without using it)
+    except Exception:   # noqa: BLE001
+        for m in ("matplotlib", "matplotlib.pyplot"):
+            sys.modules.setdefault(m, types.ModuleType(m))
     import scipy.spatial as spatial
     if not getattr(spatial.cKDTree, "_se3tn_njobs", False):
         base = spatial.cKDTree

@@ -40,6 +40,11 @@ MESH = (3, 0.06, 5)     # icosphere(subdiv, radius, seed)
 def load_predict():
     ref_shims.install()
     SG.install_stubs()
+    # other tests of the same session may have parked empty stand-ins for matplotlib (eval_ycb imports pyplot without using it):
+    # predict.py imports mpl_toolkits.mplot3d, which needs the real package
+    for name in [n for n in sys.modules if n == "matplotlib" or n.startswith("matplotlib.") or n.startswith("mpl_toolkits")]:
+        if not getattr(sys.modules[name], "__file__", None):
+            del sys.modules[name]
     U = importlib.import_module("iros20-6d-pose-tracking_amd.utils")
 
     # open3d: the point cloud Tracker.__init__ builds (predict.py:131-133)
