@@ -44,6 +44,7 @@ def make_video(root):
 
 
 def run(tmp):
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
     predict = load_predict()
     cv2 = sys.modules["cv2"]
 

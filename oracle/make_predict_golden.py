@@ -83,6 +83,7 @@ def load_predict():
 
 
 def run(tmp):
+    torch.set_num_threads(max(1, os.cpu_count() or 1))     # as oracle/make_golden.py: one thread count -> one summation order
     predict = load_predict()
     mean, std = Fx.mean_std(0)
     sd = O.make_state_dict(0, head_gain=HEAD_GAIN)
