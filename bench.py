@@ -390,8 +390,16 @@ def main():
         for hw, cin, cout, convs in ((22, 256, 256, 2), (11, 512, 512, 4)):   # AB2.conv1/2; trans|rot conv2.conv1/2
             tiles = (-(-hw // wino_tile)) ** 2
             executed_per_pair += convs * 2 * cin * cout * (nf * tiles - 9 * hw * hw)
-    executed = executed_per_pair * nb / (conv_ms_avg * 1e-3) / 1e12
     layers = eng.profile_launches(slots - 1)
+    # the 64-channel trunk launches that took the fused Winograd F(2x2) kernel (the library decides per launch: whole rounds of
+    # workgroups only; the launch name says so): 4 quadrants x 32 steps x (128 x 64 x 32) MACs per image and group instead of
+    # 44 x 44 x 64 x 64 x 9
+    TRUNK_FUSED_FLOP = 2 * 4 * 32 * 128 * 64 * 32
+    TRUNK_DIRECT_FLOP = 2 * 64 * 64 * 9 * 44 * 44
+    trunk_fused = [name for name, _ in layers if name.startswith("conv64") and "fused F(2x2)" in name]
+    for name in trunk_fused:
+        executed_per_pair += (2 if "|" in name else 1) * (TRUNK_FUSED_FLOP - TRUNK_DIRECT_FLOP)
+    executed = executed_per_pair * nb / (conv_ms_avg * 1e-3) / 1e12
     # per-launch view: executed flops of every conv launch over its own HIP-event time (averaged over the recorded steps)
     per_slot = [dict(eng.profile_launches(s_)) for s_ in range(slots)]
     spec = {   # name prefix -> (cin, cout, groups, out_hw, winograd-capable)
@@ -407,7 +415,9 @@ def main():
             continue
         cin, cout, groups, hw, wcap = spec[key]
         ms = float(np.mean([d_[name] for d_ in per_slot if name in d_]))
-        if wcap and wino_on:
+        if name in trunk_fused:
+            fl = float(TRUNK_FUSED_FLOP) * groups * nb
+        elif wcap and wino_on:
             fl = 2.0 * cin * cout * groups * (wino_tile + 2) ** 2 * (-(-hw // wino_tile)) ** 2 * nb
         else:
             fl = 2.0 * cin * cout * groups * 9 * hw * hw * nb
@@ -491,8 +501,10 @@ def main():
         eng.set_precision(se3._lib.PREC_F32)
     # and the same float32 run with the Winograd layers switched back to the direct kernels
     direct = None
-    if wino_on and not os.environ.get("SE3TN_NO_ALT"):
+    if (wino_on or trunk_fused) and not os.environ.get("SE3TN_NO_ALT"):
+        trunk_min, trunk_fill = eng.get_trunk_winograd()
         eng.set_winograd(0)
+        eng.set_trunk_winograd(0)
         for _ in range(args.warmup):
             step()
         sl = min(steps_timed, 64)
@@ -500,7 +512,7 @@ def main():
         dt3 = timed_loop(steps_timed)
         c3 = float(np.mean([eng.profile_read(s_)[0] for s_ in range(sl)]))
         eng.profile_enable(0)
-        direct = {"algorithm": "direct implicit GEMM for all ten 3x3 convs (se3tn_set_winograd(ctx, 0, 0))",
+        direct = {"algorithm": "direct implicit GEMM for all ten 3x3 convs (se3tn_set_winograd(ctx, 0, 0), se3tn_set_trunk_winograd(ctx, 0))",
                   "value": round(world * nb * steps_timed / dt3, 1), "unit": "pairs/s", "ms_per_step": round(dt3 / steps_timed * 1e3, 4),
                   "steps_timed": steps_timed, "conv_ms_per_step": round(c3, 4),
                   "achieved": round(CONV3_FLOP_PER_PAIR * nb / (c3 * 1e-3) / 1e12, 2),
@@ -510,6 +522,7 @@ def main():
             direct["parity"] = compare_with_oracle(np, parity["_oracle"], trans.cpu().numpy(), rot.cpu().numpy(),
                                                    poseB.cpu().numpy().reshape(nb, 4, 4))
         eng.set_winograd(wino_min, wino_tile)
+        eng.set_trunk_winograd(trunk_min, trunk_fill)
     assert os.environ.get("SE3TN_NOCHECK") or torch.isfinite(poseB).all()
     assert os.environ.get("SE3TN_NOCHECK") or not eng.overflow(), "f16x3 range guard fired"
 
@@ -546,7 +559,9 @@ def main():
                          "kernel": "3x3 conv family, 10 convs/step on exact-f32 v_mfma_f32_32x32x2_f32: direct implicit GEMM "
                                    "(conv3x3_slab_kernel, conv3x3_gather_s2_kernel)" +
                                    (" + Winograd F(%dx%d,3x3) for AB2.* and trans|rot conv2.* (wino_input/gemm/output_kernel)"
-                                    % (wino_tile, wino_tile) if wino_on else ""),
+                                    % (wino_tile, wino_tile) if wino_on else "") +
+                                   (" + fused Winograd F(2x2,3x3) for the 64-channel trunk (wino64_fused_kernel: %d of its 4 launches)"
+                                    % len(trunk_fused) if trunk_fused else ""),
                          # achieved / frac = the MFMA flops the family EXECUTES (Winograd layers: (tile+2)^2 multiplies per
                          # tile x tile outputs) / its HIP-event time (transform passes included) / the f32-MFMA peak
                          "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -589,7 +604,7 @@ def main():
             out["alt_precision"] = other
         if direct is not None:
             out["alt_algorithm"] = direct
-        prof = pmc_traffic(nb, wino_on)
+        prof = pmc_traffic(nb, wino_on, bool(trunk_fused))
         if prof is not None:
             out["roofline"]["traffic_from_profile"] = prof
         if world == 1 and not args.no_cpu_baseline:
@@ -647,6 +662,9 @@ class DryEngine:
 
     def get_winograd(self):
         return 8, 4
+
+    def get_trunk_winograd(self):
+        return 8, 80
 
     def overflow(self):
         return False
@@ -720,7 +738,7 @@ def check_timed_batch(np, torch, se3, O, eng, sd, nb, frames_rgb, frames_d, rend
     return res, (A, B)
 
 
-def pmc_traffic(nb, wino_on):
+def pmc_traffic(nb, wino_on, trunk_fused=False):
     """HBM bytes per step of the conv3x3 family from the newest COMMITTED rocprofv3 PMC summary
     (profiles/*_pmc.json: FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, KB, separate passes of this same
     command at batch 64).  NOT measured by this run (PMC needs rocprofv3 around the process): reported as
@@ -740,6 +758,10 @@ def pmc_traffic(nb, wino_on):
         if k not in d["write"]:
             continue
         base = k.split("<")[0]
+        if base == "wino64_fused_kernel":   # <0> = conv1 (grouped A2|B2 + B3), <1> = conv2 with the residual: two launches each
+            if trunk_fused:
+                total += 2 * (2.0 * v["FETCH_SIZE"] + d["write"][k]["WRITE_SIZE"]) * 1024.0
+            continue
         if base in wino_calls:
             if not wino_on:
                 continue
@@ -758,6 +780,8 @@ def pmc_traffic(nb, wino_on):
             continue  # the float32 instantiations only (the summary also holds the f16x3 ones)
         if wino_on and k.startswith("conv3x3_slab") and targs[0] in ("256", "512"):
             continue  # these layers ran as Winograd in the headline leg (the direct kernels are the alt_algorithm leg)
+        if trunk_fused and k.startswith("conv3x3_slab") and targs[0] == "64":
+            continue  # ran as the fused Winograd trunk kernel
         calls = 2 if targs[0] == "64" else 1
         total += calls * (2.0 * v["FETCH_SIZE"] + d["write"][k]["WRITE_SIZE"]) * 1024.0
     tag = os.path.basename(files[-1]).replace("_pmc.json", "")

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SE3TN_LIB") or os.path.join(_HERE, "libse3tracknet.so
 
 NCHW, NHWC = 0, 1
 PREC_F32, PREC_F16X3 = 0, 1
+TRUNK_WINOGRAD_DEFAULT_MIN_BATCH, TRUNK_WINOGRAD_DEFAULT_MIN_FILL = 8, 80   # as include/se3tracknet.h (tests/test_host_abi.py)
 BLUR_NONE, BLUR_BILATERAL, BLUR_GAUSSIAN = 0, 1, 2
 RES = 176
 
@@ -55,6 +56,8 @@ _SIGS = {
     "se3tn_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "se3tn_set_winograd": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "se3tn_get_winograd": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "se3tn_set_trunk_winograd": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "se3tn_get_trunk_winograd": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "se3tn_overflow": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "se3tn_keep_intermediates": (C.c_int, [C.c_void_p, C.c_int]),
     "se3tn_set_normalizers": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),

@@ -2,6 +2,7 @@
 // the .hip files.  One context per (process, device).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -32,7 +33,7 @@ enum { MAX_LAUNCHES = 24, MAX_SLOTS = 64 };
 // one captured se3tn_infer: every argument that is baked into the kernel launches
 struct GraphKey {
   const void *A, *B, *trans, *rot, *poseA, *poseB, *blob;
-  int n, layout, prec, wino;
+  int n, layout, prec, wino, wino64, wino64_fill;
   double tn, rn;
   bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
 };
@@ -72,6 +73,12 @@ struct se3tn_ctx {
   float* wino_u[4] = {nullptr, nullptr, nullptr, nullptr};  // U = G g G^T of LAB2_1, LAB2_2, LH2_1, LH2_2
   float *wino_v = nullptr, *wino_m = nullptr;   // [g][16][T][C] input tiles / per-frequency products
   const float* wino_blob = nullptr;             // the blob wino_u was derived from
+  // fused F(2x2) path of the 64-channel trunk (wino64_fused.hip) at n >= wino64_min_batch (0 = never)
+  int wino64_min_batch = SE3TN_TRUNK_WINOGRAD_DEFAULT_MIN_BATCH;
+  int wino64_min_fill = SE3TN_TRUNK_WINOGRAD_DEFAULT_MIN_FILL;
+  int num_cus = 256;   // compute units of the device (the fused trunk kernel runs one workgroup per CU: it pays in full rounds only)
+  float* wino64_u[4] = {nullptr, nullptr, nullptr, nullptr};   // F(2x2) planes of L64_1..L64_4 ([group][chunk 2][16][64][32])
+  const float* wino64_blob = nullptr;
   SplitLayout SL;                               // f16x3 mode: split panels in split_w (derived from the blob, not part of it)
   float* split_w = nullptr;
   const float* split_blob = nullptr;            // the blob split_w was derived from
@@ -130,7 +137,24 @@ static size_t wino_ws_floats(int max_batch) {
   const size_t head = (size_t)16 * 36 * 1024, ab = (size_t)16 * 121 * 256;
   return (size_t)max_batch * (head > ab ? head : ab);
 }
+static const ConvId kWino64Convs[4] = {L64_1, L64_2, L64_3, L64_4};
+static int wino64_prepare(se3tn_ctx* c, hipStream_t st) {
+  if (c->wino64_min_batch <= 0 || c->max_batch < c->wino64_min_batch || !c->blob || c->wino64_blob == c->blob) return SE3TN_OK;
+  for (int i = 0; i < 4; ++i) {
+    const Conv3& s = conv_specs()[kWino64Convs[i]];
+    const size_t per_g = (size_t)16 * s.cin * s.cout;
+    if (!c->wino64_u[i]) HIPCHK(hipMalloc((void**)&c->wino64_u[i], s.groups * per_g * sizeof(float)));
+    for (int g = 0; g < s.groups; ++g)
+      HIPCHK(launch_wino_weights(c->blob + c->L.conv_w[kWino64Convs[i]] + (size_t)g * conv3_words(s.cin, s.cout),
+                                 c->wino64_u[i] + g * per_g, s.cin, s.cout, 2, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));  // init-time
+  c->wino64_blob = c->blob;
+  return SE3TN_OK;
+}
+
 static int wino_prepare(se3tn_ctx* c, hipStream_t st) {
+  if (int rc = wino64_prepare(c, st)) return rc;
   if (c->wino_min_batch <= 0 || c->max_batch < c->wino_min_batch) return SE3TN_OK;
   if (!c->wino_v) {
     HIPCHK(hipMalloc((void**)&c->wino_v, wino_ws_floats(c->max_batch) * sizeof(float)));
@@ -225,6 +249,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
   c->max_batch = max_batch;
   c->L = blob_layout();
   c->SL = split_layout();
+  if (const char* e = std::getenv("SE3TN_TRUNK_WINOGRAD")) c->wino64_min_batch = std::atoi(e);   // developer A/B switch
   for (int i = 0; i < 8; ++i) { c->mean[i] = 0.0; c->stdv[i] = 1.0; }
   if (device >= 0) {
     hipDeviceProp_t prop;
@@ -235,6 +260,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
       delete c;
       return fail(SE3TN_E_DEVICE, "device is " + a + ", this library is built for gfx950 only");
     }
+    if (prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     e = hipSetDevice(device);
     if (e != hipSuccess) { delete c; return hipfail(e, "hipSetDevice"); }
     const size_t mb = (size_t)max_batch;
@@ -279,7 +305,7 @@ void se3tn_destroy(se3tn_ctx* c) {
                      c->head_t, c->head_f, c->logits, c->fcpart, c->part, c->blob_owned, c->split_w, c->wino_v, c->wino_m,
                      c->wino_u[0], c->wino_u[1], c->wino_u[2], c->wino_u[3],
                      c->wino_us[0], c->wino_us[1], c->wino_us[2], c->wino_us[3], c->wino_usc[0], c->wino_usc[1], c->wino_usc[2],
-                     c->wino_usc[3]};
+                     c->wino_usc[3], c->wino64_u[0], c->wino64_u[1], c->wino64_u[2], c->wino64_u[3]};
     for (float* b : bufs)
       if (b) (void)hipFree(b);
     for (auto& g : c->graphs)
@@ -334,6 +360,7 @@ int se3tn_upload_weights(se3tn_ctx* c, void* stream) {
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));  // init-time only: the host vector may go away
   c->blob = c->blob_owned;
   c->wino_blob = nullptr;  // same address, new contents
+  c->wino64_blob = nullptr;
   c->split_blob = nullptr;
   c->wino_us_blob = nullptr;
   if (int rc = wino_prepare(c, (hipStream_t)stream)) return rc;
@@ -349,6 +376,7 @@ int se3tn_bind_weights(se3tn_ctx* c, const void* device_blob, size_t bytes) {
     return fail(SE3TN_E_SHAPE, "se3tn_bind_weights: bad blob header");
   c->blob = (const float*)device_blob;
   c->wino_blob = nullptr;
+  c->wino64_blob = nullptr;
   c->split_blob = nullptr;
   c->wino_us_blob = nullptr;
   if (int rc = wino_prepare(c, nullptr)) return rc;
@@ -363,6 +391,31 @@ int se3tn_set_winograd(se3tn_ctx* c, int min_batch, int tile) {
   if (c->device < 0) return SE3TN_OK;
   if (int rc = wino_prepare(c, nullptr)) return rc;
   return split_prepare(c, nullptr);
+}
+
+// The fused trunk kernel occupies a CU per workgroup (123 KB of LDS) for ~64 us whatever the batch: it beats the direct kernels when
+// its 4 n groups workgroups fill whole rounds of the CUs (measured, scripts/trunk_sweep.sh: n = 64 -> 2 | 1 rounds, 131 | 66 us vs
+// 155 | 81 us direct; n = 32 grouped 66 vs 81; but n = 48 grouped = 1.5 rounds 124 vs 117, n = 32 single = half a round 63 vs 45).
+static bool wino64_pays(const se3tn_ctx* c, int n, int groups) {
+  if (c->wino64_min_batch <= 0 || n < c->wino64_min_batch) return false;
+  const long wgs = 4L * n * groups, rounds = (wgs + c->num_cus - 1) / c->num_cus;
+  return 100 * wgs >= (long)c->wino64_min_fill * rounds * c->num_cus;   // the rounds are at least min_fill % full
+}
+
+int se3tn_set_trunk_winograd(se3tn_ctx* c, int min_batch, int min_fill_percent) {
+  if (!c || min_batch < 0 || min_fill_percent < 0 || min_fill_percent > 100)
+    return fail(SE3TN_E_ARG, "se3tn_set_trunk_winograd: min_batch >= 0, 0 <= min_fill_percent <= 100");
+  c->wino64_min_batch = min_batch;
+  c->wino64_min_fill = min_fill_percent;
+  if (c->device < 0) return SE3TN_OK;
+  return wino_prepare(c, nullptr);
+}
+
+int se3tn_get_trunk_winograd(const se3tn_ctx* c, int* min_batch, int* min_fill_percent) {
+  if (!c || !min_batch || !min_fill_percent) return fail(SE3TN_E_ARG, "se3tn_get_trunk_winograd: bad argument");
+  *min_batch = c->wino64_min_batch;
+  *min_fill_percent = c->wino64_min_fill;
+  return SE3TN_OK;
 }
 
 int se3tn_get_winograd(const se3tn_ctx* c, int* min_batch, int* tile) {
@@ -494,7 +547,8 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
   GraphKey key;
   std::memset(&key, 0, sizeof(key));
   key.A = A; key.B = B; key.trans = trans; key.rot = rot; key.poseA = poseA; key.poseB = poseB; key.blob = c->blob;
-  key.n = n; key.layout = layout; key.prec = c->prec; key.wino = (c->wino_min_batch * 8 + c->wino_tile) * 2 + (c->keep_intermediates ? 1 : 0); key.tn = c->tn; key.rn = c->rn;
+  key.n = n; key.layout = layout; key.prec = c->prec;
+  key.wino = ((c->wino_min_batch * 8 + c->wino_tile) * 2 + (c->keep_intermediates ? 1 : 0)); key.wino64 = c->wino64_min_batch; key.wino64_fill = c->wino64_min_fill; key.tn = c->tn; key.rn = c->rn;
   hipStream_t st = (hipStream_t)stream;
   for (auto& g : c->graphs) {
     if (!(g.key == key)) continue;
@@ -599,6 +653,15 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
       hipError_t e = launch_wino_conv(w, epi, st);
       if (e != hipSuccess) return hipfail(e, name);
       return prof_mark(c, st, name, true);
+    }
+    if (id <= L64_4 && !fast && wino64_pays(c, n, s.groups) && c->wino64_blob == c->blob && stride == 1 && hin == S2 && epi != 2) {
+      const int slot64 = (int)id - (int)L64_1;
+      hipError_t e = launch_wino64(in, in_ld, in_gs, c->wino64_u[slot64], (long long)16 * s.cin * s.cout, W + L.conv_b[id], s.cout, res,
+                                   res_ld, res_gs, out, out_ld, out_gs, n, s.groups, epi, st);
+      if (e != hipSuccess) return hipfail(e, name);
+      static const char* const fused_names[4] = {"conv64 A2.conv1|B2.conv1 [fused F(2x2)]", "conv64 A2.conv2|B2.conv2 [fused F(2x2)]",
+                                                 "conv64 B3.conv1 [fused F(2x2)]", "conv64 B3.conv2 [fused F(2x2)]"};
+      return prof_mark(c, st, fused_names[slot64], true);   // (the profile says which algorithm a launch took)
     }
     ConvArgs a{};
     a.in = in; a.w = W + L.conv_w[id]; a.bias = W + L.conv_b[id];

@@ -1,0 +1,314 @@
+// Fused Winograd F(2x2,3x3) for the 64 -> 64 channel 3x3 stride-1 convolutions of the trunk (convA2 / convB2 / convB3 of
+// Se3TrackNet, se3_tracknet.py:59-64 via network_modules.py:86-120) on the 44 x 44 maps, for large batches.
+//
+// Why a different kernel.  The direct 64-channel kernels (conv3x3_slab_kernel<64,...>) sit at 0.70 of the f32 MFMA peak and cannot
+// move: K = 576 per tile and 968 / 484 tiles on 256 workgroups = 3.78 / 1.89 rounds.  The plain Winograd route
+// (transform pass -> batched GEMM -> transform pass, wino_mfma.hip) does not pay at 64 channels: the V / M planes are 4x the activation
+// and the 16 GEMMs have K = 64 -- the passes alone cost what the direct kernel costs.  This kernel keeps EVERYTHING on the chip:
+//
+//   workgroup = one image x one 22 x 22-pixel quadrant x one group = 11 x 11 Winograd tiles (121 of 128 MFMA rows) x 64 couts
+//               => 4 workgroups per image and group: 512 (A2|B2) or 256 (B3) workgroups = exactly 2 / 1 rounds on 256 CUs
+//   per 32-channel chunk: the 24 x 24-pixel input patch is DMA'd into LDS once (73.7 KB)
+//   per (chunk, frequency f = 4 i + j), 32 steps per tile:
+//       V_f = (B^T d B)_ij  of the 121 tiles x 32 channels, computed from the patch by the VALU straight into an LDS operand tile
+//             (B^T rows have two +-1 entries: V is a signed sum of 4 patch pixels)                          [double-buffered, 2 x 16 KB]
+//       U_f chunk [64 couts x 32] DMA'd from the pre-transformed weights (U = G g G^T, float64 -> float32 once)   [double-buffered, 2 x 8 KB]
+//       M_f = V_f U_f on v_mfma_f32_32x32x2_f32: 8 waves = 4 row blocks x 2 cout blocks, one 32 x 32 block each
+//       Y[y][x] += A^T[y][i] A^T[x][j] M_f   in registers (A^T entries are 0 / +-1): the 16 M_f never exist at the same time
+//   at the end + bias (+ residual), ReLU, float4 stores of the 2 x 2 outputs per tile.
+//
+// MFMA work: 16 x 2 x (128 x 64 x 32) per tile = 2.25x less than direct (incl. the 7 unused rows).  Float32 throughout; rounding as
+// F(2x2) in wino_mfma.hip (1.5e-7 of the layer's largest activation).  Operand tiles use the same 128-byte rows, XOR swizzle and
+// fragment layout as conv3x3_mfma.hip / wino_mfma.hip.
+#include "mfma_common.h"
+
+namespace se3tn {
+
+namespace {
+constexpr int W64_TILES = 11;                 // Winograd tiles per quadrant edge
+constexpr int W64_PATCH = 2 * W64_TILES + 2;  // 24 input pixels per edge
+constexpr int W64_PATCH_FLOATS = W64_PATCH * W64_PATCH * 32;   // 18,432
+constexpr int W64_V_FLOATS = 128 * 32, W64_U_FLOATS = 64 * 32;
+// (U tiles fetched three steps ahead into four buffers with counted vmcnt waits + raw s_barrier: measured SLOWER, 0.152 vs 0.141 ms for the
+// grouped launch -- as everywhere in this library the K-loop does not wait for data, it loses issue slots to the DMA)
+constexpr int W64_UBUFS = 2;
+constexpr int W64_LDS_FLOATS = W64_PATCH_FLOATS + 2 * W64_V_FLOATS + W64_UBUFS * W64_U_FLOATS;   // 30,720 floats = 122,880 B
+constexpr size_t W64_LDS_BYTES = sizeof(float) * W64_LDS_FLOATS;
+}  // namespace
+
+// B^T row i of F(2x2): two non-zero entries (r0, +-1), (r1, +-1):  i=0: d0 - d2;  1: d1 + d2;  2: -d1 + d2;  3: d1 - d3
+__device__ __forceinline__ void bt_row(int i, int& r0, int& r1, float& c0, float& c1) {
+  r0 = i == 0 ? 0 : 1;
+  r1 = i == 3 ? 3 : 2;
+  c0 = i == 2 ? -1.f : 1.f;
+  c1 = (i == 0 || i == 3) ? -1.f : 1.f;
+}
+// A^T column i of F(2x2): A^T = [[1,1,1,0],[0,1,-1,-1]]
+__device__ __forceinline__ void at_col(int i, float& a0, float& a1) {
+  a0 = i == 3 ? 0.f : 1.f;
+  a1 = i == 0 ? 0.f : (i == 1 ? 1.f : -1.f);
+}
+
+struct Wino64Args {
+  const float* in;    // padded NHWC [n][46][46][in_ld], channel offset of group 0 applied
+  const float* U;     // group 0: [chunk 2][f 16][cout 64][32]
+  const float* bias;  // group 0: [64]
+  const float* res;   // residual (geometry of out) or nullptr
+  float* out;         // padded NHWC
+  int in_ld, res_ld, out_ld;
+  int in_gs, res_gs, out_gs, bias_gs;
+  long long u_gs;
+  int n, groups;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512) void wino64_fused_kernel(const Wino64Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;
+  float* Vb = smem + W64_PATCH_FLOATS;
+  float* Ub = Vb + 2 * W64_V_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = wid >> 1, cbk = wid & 1;      // this wave's 32 x 32 block: tiles 32 rb .. 32 rb + 31, couts 32 cbk .. 32 cbk + 31
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  const int g = blockIdx.x % a.groups, rest = blockIdx.x / a.groups;
+  const int quad = rest & 3, img = rest >> 2;
+  const int y0 = (quad >> 1) * 2 * W64_TILES, x0 = (quad & 1) * 2 * W64_TILES;   // padded coordinates of the patch origin
+  constexpr int HP = 46;
+  const float* __restrict__ in = a.in + (size_t)g * a.in_gs + ((size_t)(img * HP + y0) * HP + x0) * a.in_ld;
+  const float* __restrict__ Ug = a.U + (size_t)g * a.u_gs;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+  // ---- DMA geometry ------------------------------------------------------------------------------------------------------
+  // patch piece id = tid + 512 j (j < 9): pixel id >> 3 (row-major in the 24 x 24 patch), 16-byte slot id & 7 -> LDS linear
+  // U tile: thread -> row tid >> 3 (cout), LDS slot tid & 7 holds channel block (tid & 7) ^ ((row >> 1) & 7)
+  const int ur = tid >> 3;
+  const unsigned uvoff = (unsigned)((ur * 32 + (((tid & 7) ^ ((ur >> 1) & 7)) << 2)) * 4);
+
+#define W64_ISSUE_PATCH(CH)                                                                                     \
+  {                                                                                                            \
+    const float* pb_ = in + (CH) * 32;                                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < 9; ++j_) {   /* 4608 pieces = 9 x 512 */                             \
+      const int id_ = tid + 512 * j_, px_ = id_ >> 3, py_ = px_ / W64_PATCH, pxx_ = px_ - py_ * W64_PATCH;      \
+      const int xs_ = pxx_ < 12 ? 2 * pxx_ : 2 * pxx_ - 23;   /* LDS column pxx_ holds patch column xs_ */        \
+      glds16<0>(pb_, (unsigned)(((py_ * HP + xs_) * a.in_ld + (id_ & 7) * 4) * 4),                              \
+                lds0 + (unsigned)((wid * 64 + 512 * j_) * 16));                                                 \
+    }                                                                                                          \
+  }
+#define W64_ISSUE_U(CH, F, BUFI)                                                                                \
+  glds16<0>(Ug + (size_t)((CH) * 16 + (F)) * W64_U_FLOATS, uvoff,                                              \
+            lds0 + (unsigned)((W64_PATCH_FLOATS + 2 * W64_V_FLOATS + (BUFI) * W64_U_FLOATS + wid * 256) * 4));
+
+  // ---- input transform tasks: (tile t, channel block cb) = id >> 3, id & 7 for id = tid, tid + 512.  Branch-free: the 56 ids past
+  // tile 120 read tile 120's window and write operand rows 121..127, which the MFMA computes and nobody stores.
+  int tpix[2], tdst[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int tt = (tid + 512 * j) >> 3, tcb = tid & 7;
+    const int ttr = tt < W64_TILES * W64_TILES ? tt : W64_TILES * W64_TILES - 1;
+    const int tty = ttr / W64_TILES, ttx = ttr - tty * W64_TILES;
+    tpix[j] = ((2 * tty) * W64_PATCH + ttx) * 32 + tcb * 4;                 // float index of window pixel (0,0), this channel block
+    tdst[j] = tt * 32 + ((tcb ^ ((tt >> 1) & 7)) << 2);                       // swizzled operand row t
+  }
+  // offsets / coefficients of frequency F's B^T entries (uniform: scalar registers)
+#define W64_BT(F)                                                                                               \
+  int r0_, r1_, s0_, s1_;                                                                                      \
+  float cr0_, cr1_, cs0_, cs1_;                                                                                \
+  bt_row((F) >> 2, r0_, r1_, cr0_, cr1_);                                                                      \
+  bt_row((F) & 3, s0_, s1_, cs0_, cs1_);                                                                       \
+  const int q0_ = (s0_ >> 1) + 12 * (s0_ & 1), q1_ = (s1_ >> 1) + 12 * (s1_ & 1);   /* LDS columns */           \
+  const int o00_ = (r0_ * W64_PATCH + q0_) * 32, o01_ = (r0_ * W64_PATCH + q1_) * 32;                          \
+  const int o10_ = (r1_ * W64_PATCH + q0_) * 32, o11_ = (r1_ * W64_PATCH + q1_) * 32;                          \
+  const float c00_ = cr0_ * cs0_, c01_ = cr0_ * cs1_, c10_ = cr1_ * cs0_, c11_ = cr1_ * cs1_;
+#define W64_TR_LOAD(D)                                                                                          \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                            \
+    D[j_][0] = *reinterpret_cast<const float4*>(patch + tpix[j_] + o00_);                                       \
+    D[j_][1] = *reinterpret_cast<const float4*>(patch + tpix[j_] + o01_);                                       \
+    D[j_][2] = *reinterpret_cast<const float4*>(patch + tpix[j_] + o10_);                                       \
+    D[j_][3] = *reinterpret_cast<const float4*>(patch + tpix[j_] + o11_);                                       \
+  }
+#define W64_TR_STORE(D, VBUF)                                                                                   \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                            \
+    float4 v_;                                                                                                 \
+    v_.x = c00_ * D[j_][0].x + c01_ * D[j_][1].x + c10_ * D[j_][2].x + c11_ * D[j_][3].x;                       \
+    v_.y = c00_ * D[j_][0].y + c01_ * D[j_][1].y + c10_ * D[j_][2].y + c11_ * D[j_][3].y;                       \
+    v_.z = c00_ * D[j_][0].z + c01_ * D[j_][1].z + c10_ * D[j_][2].z + c11_ * D[j_][3].z;                       \
+    v_.w = c00_ * D[j_][0].w + c01_ * D[j_][1].w + c10_ * D[j_][2].w + c11_ * D[j_][3].w;                       \
+    *reinterpret_cast<float4*>(Vb + (VBUF) * W64_V_FLOATS + tdst[j_]) = v_;                                     \
+  }
+#define W64_TRANSFORM(F, VBUF)                                                                                  \
+  {                                                                                                            \
+    W64_BT(F)                                                                                                  \
+    float4 d_[2][4];                                                                                           \
+    W64_TR_LOAD(d_)                                                                                            \
+    W64_TR_STORE(d_, VBUF)                                                                                     \
+  }
+
+  // ---- fragment offsets of the four 8-k groups of a step (as wino_gemm_kernel) ------------------------------------------------------
+  const int X = (l31 >> 1) & 7;
+  const int lo = (hh ^ (X & 1)) * 4, xk = X >> 1;
+  const int fo0 = ((0 ^ xk) << 3) + lo, fo1 = ((1 ^ xk) << 3) + lo, fo2 = ((2 ^ xk) << 3) + lo, fo3 = ((3 ^ xk) << 3) + lo;
+
+  float Y[16][4];
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) Y[e][o] = 0.f;
+
+  // ---- prologue ------------------------------------------------------------------------------------------------------------
+  W64_ISSUE_PATCH(0)
+  W64_ISSUE_U(0, 0, 0)
+  wait_dma_and_barrier();
+  W64_TRANSFORM(0, 0)
+  __syncthreads();
+
+  // 32 steps = 2 chunks x 16 frequencies, software-pipelined inside every wave: while the matrix pipe works through the 16 MFMAs of
+  // step s (one 32 x 32 block over the step's 32 channels), the vector ALU folds the products of step s - 1 into Y and builds this
+  // thread's two pieces of the operand tile of step s + 1.  The three are independent inside a step, the step is one basic block,
+  // and scheduling fences keep "1 MFMA, then 4 fold FMAs + 2-3 transform ops" sixteen times in that order.
+  // (Knock-out measurements of the un-pipelined kernel -- matrix phase, then fold, then transform: the grouped launch takes 132 us;
+  // 78 us without the MFMAs, 109 us without the transform, 123 us without the fold: nothing overlapped, all waves of a workgroup
+  // meet at the step barrier in the same phase.)
+  f32x16 accA, accB;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) accB[e] = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define W64_FOLD(PREV, F)                                                                                       \
+  {                                                                                                            \
+    float ay0_, ay1_, ax0_, ax1_;                                                                              \
+    at_col((F) >> 2, ay0_, ay1_);                                                                              \
+    at_col((F) & 3, ax0_, ax1_);                                                                               \
+    const float k00_ = ay0_ * ax0_, k01_ = ay0_ * ax1_, k10_ = ay1_ * ax0_, k11_ = ay1_ * ax1_;                \
+    _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                        \
+      const float m_ = PREV[e_];                                                                               \
+      Y[e_][0] += k00_ * m_; Y[e_][1] += k01_ * m_; Y[e_][2] += k10_ * m_; Y[e_][3] += k11_ * m_;              \
+    }                                                                                                          \
+  }
+#define W64_MFMA(ACC)                                                                                        \
+  ACC = q_ == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[0], pv_[0], zero16, 0, 0, 0)                         \
+                : __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[q_], pv_[q_], ACC, 0, 0, 0);
+#define W64_STEP(S, ACC, PREV)                                                                                  \
+  {                                                                                                            \
+    const int s_ = (S), buf = s_ & 1, sn = s_ + 1;                                                             \
+    if (sn < 32) W64_ISSUE_U(sn >> 4, sn & 15, buf ^ 1)                                                         \
+    if (s_ == 15) W64_ISSUE_PATCH(1) /* the patch buffer is free: the transform of step 15 ran during step 14 */ \
+    {                                                                                                          \
+      const float* pP = Vb + buf * W64_V_FLOATS + (rb * 32 + l31) * 32;                                        \
+      const float* pW = Ub + buf * W64_U_FLOATS + (cbk * 32 + l31) * 32;                                       \
+      float pv_[16], wv_[16], d_[2][4][4], v_[2][4];                                                           \
+      *reinterpret_cast<float4*>(pv_ + 0) = *reinterpret_cast<const float4*>(pP + fo0);                         \
+      *reinterpret_cast<float4*>(wv_ + 0) = *reinterpret_cast<const float4*>(pW + fo0);                         \
+      *reinterpret_cast<float4*>(pv_ + 4) = *reinterpret_cast<const float4*>(pP + fo1);                         \
+      *reinterpret_cast<float4*>(wv_ + 4) = *reinterpret_cast<const float4*>(pW + fo1);                         \
+      *reinterpret_cast<float4*>(pv_ + 8) = *reinterpret_cast<const float4*>(pP + fo2);                         \
+      *reinterpret_cast<float4*>(wv_ + 8) = *reinterpret_cast<const float4*>(pW + fo2);                         \
+      *reinterpret_cast<float4*>(pv_ + 12) = *reinterpret_cast<const float4*>(pP + fo3);                        \
+      *reinterpret_cast<float4*>(wv_ + 12) = *reinterpret_cast<const float4*>(pW + fo3);                        \
+      W64_BT(sn & 15)   /* (step 15 transforms a patch that is being replaced and step 31 one nobody reads: harmless, branch-free) */ \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                        \
+        *reinterpret_cast<float4*>(d_[j_][0]) = *reinterpret_cast<const float4*>(patch + tpix[j_] + o00_);      \
+        *reinterpret_cast<float4*>(d_[j_][1]) = *reinterpret_cast<const float4*>(patch + tpix[j_] + o01_);      \
+        *reinterpret_cast<float4*>(d_[j_][2]) = *reinterpret_cast<const float4*>(patch + tpix[j_] + o10_);      \
+        *reinterpret_cast<float4*>(d_[j_][3]) = *reinterpret_cast<const float4*>(patch + tpix[j_] + o11_);      \
+      }                                                                                                        \
+      float ay0_, ay1_, ax0_, ax1_;                                                                            \
+      at_col(((s_ + 15) & 15) >> 2, ay0_, ay1_);   /* fold: products of step s - 1 (zeros before step 0) */      \
+      at_col(((s_ + 15) & 15) & 3, ax0_, ax1_);                                                                \
+      const float k00_ = ay0_ * ax0_, k01_ = ay0_ * ax1_, k10_ = ay1_ * ax0_, k11_ = ay1_ * ax1_;              \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                       \
+        W64_MFMA(ACC)                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (q_ < 8) {   /* first half of the matrix phase: fold (no LDS data needed) */                          \
+          _Pragma("unroll") for (int e_ = 2 * q_; e_ < 2 * q_ + 2; ++e_) {                                      \
+            const float m_ = PREV[e_];                                                                         \
+            Y[e_][0] += k00_ * m_; Y[e_][1] += k01_ * m_; Y[e_][2] += k10_ * m_; Y[e_][3] += k11_ * m_;        \
+            /* pin the fold here: left alone the compiler sinks all 64 FMAs below the step's barrier */        \
+            asm volatile("" : "+v"(Y[e_][0]), "+v"(Y[e_][1]), "+v"(Y[e_][2]), "+v"(Y[e_][3]));                  \
+          }                                                                                                    \
+        } else {        /* second half: the operand tile of step s + 1 (its window reads have landed by now) */ \
+          const int j_ = (q_ - 8) >> 2, x_ = (q_ - 8) & 3;                                                     \
+          v_[j_][x_] = c00_ * d_[j_][0][x_] + c01_ * d_[j_][1][x_] + c10_ * d_[j_][2][x_] + c11_ * d_[j_][3][x_]; \
+          asm volatile("" : "+v"(v_[j_][x_]));                                                                 \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+      }                                                                                                        \
+      *reinterpret_cast<float4*>(Vb + (buf ^ 1) * W64_V_FLOATS + tdst[0]) = *reinterpret_cast<float4*>(v_[0]); \
+      *reinterpret_cast<float4*>(Vb + (buf ^ 1) * W64_V_FLOATS + tdst[1]) = *reinterpret_cast<float4*>(v_[1]); \
+    }                                                                                                          \
+    if (sn < 32) wait_dma_and_barrier();                                                                         \
+    if (sn == 16) { /* chunk boundary: the second patch has landed (waited above): only now can its first tile be built */ \
+      W64_TRANSFORM(0, buf ^ 1)                                                                                \
+      __syncthreads();                                                                                         \
+    }                                                                                                          \
+  }
+  for (int s2 = 0; s2 < 32; s2 += 2) {
+    W64_STEP(s2, accA, accB)
+    W64_STEP(s2 + 1, accB, accA)
+  }
+  W64_FOLD(accB, 15)    // step 31
+#undef W64_STEP
+#undef W64_MFMA
+#undef W64_FOLD
+#undef W64_ISSUE_PATCH
+#undef W64_ISSUE_U
+#undef W64_TRANSFORM
+#undef W64_TR_LOAD
+#undef W64_TR_STORE
+#undef W64_BT
+
+  // ---- epilogue: every wave stores its own 32 tiles x 32 couts (bias, residual, ReLU; float4 of 4 couts per store) ----------------
+  const float* __restrict__ bias = a.bias + (size_t)g * a.bias_gs;
+  const float* __restrict__ res = (EPI == 1) ? a.res + (size_t)g * a.res_gs : nullptr;
+  float* __restrict__ out = a.out + (size_t)g * a.out_gs;
+  const int t = rb * 32 + l31;
+  if (t < W64_TILES * W64_TILES) {
+    const int ty = t / W64_TILES, tx = t - ty * W64_TILES;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int oy = y0 + 2 * ty + (o >> 1) + 1, ox = x0 + 2 * tx + (o & 1) + 1;   // padded coordinates of the output pixel
+      const size_t pix = (size_t)(img * HP + oy) * HP + ox;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = cbk * 32 + q * 8 + hh * 4;
+        const float4 b = *reinterpret_cast<const float4*>(bias + c);
+        float4 v = make_float4(Y[4 * q + 0][o] + b.x, Y[4 * q + 1][o] + b.y, Y[4 * q + 2][o] + b.z, Y[4 * q + 3][o] + b.w);
+        if (EPI == 1) {
+          const float4 r = *reinterpret_cast<const float4*>(res + pix * a.res_ld + c);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<float4*>(out + pix * a.out_ld + c) = v;
+      }
+    }
+  }
+}
+
+// in / res / out: padded NHWC tensors of the 44 x 44 maps; U: F(2x2) planes [chunk][16][64][32] per group (launch_wino_weights, m = 2)
+hipError_t launch_wino64(const float* in, int in_ld, int in_gs, const float* U, long long u_gs, const float* bias, int bias_gs,
+                         const float* res, int res_ld, int res_gs, float* out, int out_ld, int out_gs, int n, int groups, int epi,
+                         hipStream_t st) {
+  Wino64Args a{};
+  a.in = in; a.U = U; a.bias = bias; a.res = res; a.out = out;
+  a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
+  a.in_gs = in_gs; a.res_gs = res_gs; a.out_gs = out_gs; a.bias_gs = bias_gs; a.u_gs = u_gs;
+  a.n = n; a.groups = groups;
+  static PerDeviceOnce attr0, attr1;
+  auto k0 = wino64_fused_kernel<0>;
+  auto k1 = wino64_fused_kernel<1>;
+  bool* done = (epi == 1 ? attr1 : attr0).current();
+  if (!done || !*done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(epi == 1 ? k1 : k0), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)W64_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    if (done) *done = true;
+  }
+  const dim3 grid(n * 4 * groups);
+  if (epi == 1) hipLaunchKernelGGL(k1, grid, dim3(512), W64_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(k0, grid, dim3(512), W64_LDS_BYTES, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace se3tn

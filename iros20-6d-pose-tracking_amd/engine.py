@@ -139,6 +139,19 @@ class Engine:
         SE3TN_WINOGRAD_DEFAULT_MIN_BATCH / _TILE of include/se3tracknet.h."""
         check(self.lib.se3tn_set_winograd(self._h, int(min_batch), int(tile)), "se3tn_set_winograd")
 
+    def set_trunk_winograd(self, min_batch, min_fill_percent=None):
+        """Launches of the 64-channel trunk at n >= min_batch take the fused Winograd F(2x2,3x3) kernel when their workgroups fill
+        whole rounds of the CUs to >= min_fill_percent (None = SE3TN_TRUNK_WINOGRAD_DEFAULT_MIN_FILL, 0 = every such launch);
+        min_batch 0 = always the direct kernels."""
+        fill = _lib.TRUNK_WINOGRAD_DEFAULT_MIN_FILL if min_fill_percent is None else int(min_fill_percent)
+        check(self.lib.se3tn_set_trunk_winograd(self._h, int(min_batch), fill), "se3tn_set_trunk_winograd")
+
+    def get_trunk_winograd(self):
+        """(min_batch, min_fill_percent) currently in force."""
+        mb, fp = C.c_int(), C.c_int()
+        check(self.lib.se3tn_get_trunk_winograd(self._h, C.byref(mb), C.byref(fp)), "se3tn_get_trunk_winograd")
+        return mb.value, fp.value
+
     def get_winograd(self):
         """(min_batch, tile) currently in force."""
         mb, t = C.c_int(), C.c_int()

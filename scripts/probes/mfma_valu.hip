@@ -1,0 +1,66 @@
+// Probe: does vector-ALU work placed between the MFMAs of a wave run in the shadow of the matrix pipe?
+// 256 workgroups x 8 waves (2 per SIMD, as wino64_fused_kernel), every wave: ITER x { 16 x [ v_mfma_f32_32x32x2_f32 on ONE accumulator
+// (a dependent chain, as a 32 x 32 block per wave has), then NV independent v_fma_f32 ] }.
+// build: hipcc -O3 --offload-arch=gfx950 scripts/probes/mfma_valu.hip -o scripts/probes/bin/mfma_valu
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NV, int NACC, bool MFMA>
+__global__ __launch_bounds__(512) void k(float* out, int iters) {
+  f32x16 acc[NACC];
+  for (int c = 0; c < NACC; ++c)
+    for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+  float a = threadIdx.x * 1e-3f, b = 1.0f + blockIdx.x * 1e-6f;
+  float y[8];
+  for (int i = 0; i < 8; ++i) y[i] = i;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if (MFMA) acc[q % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q % NACC], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(y[v & 7]) : "v"(a), "v"(b));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float s = 0.f;
+  for (int c = 0; c < NACC; ++c)
+    for (int e = 0; e < 16; ++e) s += acc[c][e];
+  for (int i = 0; i < 8; ++i) s += y[i];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+template <int NV, int NACC, bool MFMA>
+void run(const char* name, float* out) {
+  const int iters = 4000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int r = 0; r < 3; ++r) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<NV, NACC, MFMA>), dim3(256), dim3(512), 0, 0, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  const double mf = MFMA ? 256.0 * 8 * iters * 16 * 4096.0 : 0.0;
+  const double clk_per_group = best * 1e-3 * 2.4e9 / (iters * 16.0);   // per (MFMA + NV VALU) slot of one wave pair, at 2.4 GHz
+  printf("%-44s %8.3f ms  %7.1f TF   %6.1f clk per slot (2 waves/SIMD, 2.4 GHz nominal)\n", name, best, mf / best * 1e-9, clk_per_group);
+}
+
+int main() {
+  float* out; hipMalloc(&out, 256 * 512 * 4);
+  run<0, 1, true>("MFMA chain only", out);
+  run<2, 1, true>("MFMA chain + 2 VALU each", out);
+  run<4, 1, true>("MFMA chain + 4 VALU each", out);
+  run<8, 1, true>("MFMA chain + 8 VALU each", out);
+  run<12, 1, true>("MFMA chain + 12 VALU each", out);
+  run<16, 1, true>("MFMA chain + 16 VALU each", out);
+  run<8, 2, true>("2 MFMA chains + 8 VALU each", out);
+  run<4, 1, false>("4 VALU only", out);
+  run<8, 1, false>("8 VALU only", out);
+  run<16, 1, false>("16 VALU only", out);
+  return 0;
+}

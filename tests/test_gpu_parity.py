@@ -191,12 +191,70 @@ def test_winograd_path_vs_direct_and_oracle(se3, golden_dir, tile):
     print("F(%dx%d): max |d logit| Winograd vs direct = %.2e, |d trans| = %.2e" % (tile, tile, e0, e1))
 
 
+def test_fused_trunk_winograd_vs_direct_and_oracle(se3, golden_dir):
+    """The large-batch algorithm of the 64-channel trunk (fused Winograd F(2x2,3x3), wino64_fused.hip) forced on at small n
+    (min_fill 0): the trunk's buffers against the direct kernels on the same engine, the logits against the oracle and the
+    reference-made golden; the zero borders of the padded maps stay zero; and the default rule picks it per launch (whole rounds of
+    workgroups only)."""
+    sd = O.make_state_dict(0)
+    m = se3.Se3TrackNet(176, max_batch=64)
+    m.load_state_dict(sd)
+    m.cuda(0).eval()
+    eng = m.engine
+    g = np.load(os.path.join(golden_dir, "network_n3.npz"))
+    A, B = Fx.net_inputs(1, 3)
+    ref = O.forward(sd, A, B, intermediates=True)
+    eng.set_trunk_winograd(0)
+    od = m(A.cuda(), B.cuda())
+    q_d, t_d = _nchw(eng.debug_buffer("q64", 3), 1).clone(), _nchw(eng.debug_buffer("t64", 3), 1).clone()
+    lg_d, feat_d = eng.logits(3).cpu().clone(), od["feature"].cpu().clone()
+    eng.set_trunk_winograd(1, 0)
+    ow = m(A.cuda(), B.cuda())
+    q_w, t_w = _nchw(eng.debug_buffer("q64", 3), 1), _nchw(eng.debug_buffer("t64", 3), 1)   # _nchw: borders still zero
+    lg_w = eng.logits(3).cpu()
+    assert not torch.equal(q_w, q_d), "the fused trunk path did not run"
+    SCALE = 2e-5   # F(2x2) transform-amplified f32 rounding, relative to the layer's largest activation
+    _close("q64 vs direct", q_w, q_d, ACT_RTOL, 0, SCALE)
+    _close("t64 vs direct", t_w, t_d, ACT_RTOL, 0, SCALE)
+    _close("feature", ow["feature"].cpu(), ref["feature"], ACT_RTOL, 0, SCALE)
+    _close("feature vs direct", ow["feature"].cpu(), feat_d, ACT_RTOL, 0, SCALE)
+    e0 = _close("logits vs direct", lg_w, lg_d, 0, 2e-5)
+    _close("trans_logit", lg_w[:, :3], ref["trans_logit"], 0, NET_TOL)
+    _close("rot_logit", lg_w[:, 3:], ref["rot_logit"], 0, NET_TOL)
+    _close("trans vs golden", ow["trans"].cpu(), torch.from_numpy(g["trans"]), 0, NET_TOL)
+    _close("rot vs golden", ow["rot"].cpu(), torch.from_numpy(g["rot"]), 0, NET_TOL)
+    # every pair of a forced batch of 5 equals that pair alone through the same kernel (a workgroup never spans two images): bitwise
+    A5, B5 = Fx.net_inputs(9, 5)
+    m(A5.cuda(), B5.cuda(), return_feature=False)
+    q5 = eng.debug_buffer("q64", 5).clone()
+    l5 = eng.logits(5).cpu().clone()
+    m(A5[3:4].cuda(), B5[3:4].cuda(), return_feature=False)
+    assert torch.equal(eng.debug_buffer("q64", 1)[0], q5[3]), "fused trunk: a pair's result depends on its batch"
+    ref5 = O.forward(sd, A5, B5)
+    _close("n5 logits", l5, torch.cat([ref5["trans_logit"], ref5["rot_logit"]], 1), 0, NET_TOL)
+    # the default rule: at n = 64 all four trunk launches fill 2 | 1 rounds of the 256 CUs -> fused; at n = 48 (1.5 | 0.75 rounds)
+    # none does; at n = 32 only the grouped A2|B2 launches (one full round)
+    eng.set_trunk_winograd(se3._lib.TRUNK_WINOGRAD_DEFAULT_MIN_BATCH)
+    A64, B64 = Fx.net_inputs(5, 64)
+    Ac, Bc = A64.cuda(), B64.cuda()
+    for n, want in ((64, 4), (48, 0), (32, 2), (4, 0)):
+        eng.profile_enable(1)
+        m(Ac[:n], Bc[:n], return_feature=False)
+        torch.cuda.synchronize()
+        names = [nm for nm, _ in eng.profile_launches(0) if nm.startswith("conv64")]
+        eng.profile_enable(0)
+        assert len(names) == 4 and sum("fused F(2x2)" in nm for nm in names) == want, (n, names)
+    print("fused trunk F(2x2): max |d logit| vs direct = %.2e" % e0)
+
+
 def _modes(se3, eng):
     """The three arithmetic configurations of the engine: (name, enter, leave)."""
     wmin, wtile = eng.get_winograd()
+    tw = eng.get_trunk_winograd()
     return [
-        ("f32 default (Winograd F(4x4) blocks from n >= %d)" % wmin, lambda: None, lambda: None),
-        ("f32 direct kernels only", lambda: eng.set_winograd(0), lambda: eng.set_winograd(wmin, wtile)),
+        ("f32 default (Winograd F(4x4) blocks from n >= %d, fused F(2x2) trunk in full rounds)" % wmin, lambda: None, lambda: None),
+        ("f32 direct kernels only", lambda: (eng.set_winograd(0), eng.set_trunk_winograd(0)),
+         lambda: (eng.set_winograd(wmin, wtile), eng.set_trunk_winograd(*tw))),
         ("f16x3", lambda: eng.set_precision(se3._lib.PREC_F16X3), lambda: eng.set_precision(se3._lib.PREC_F32)),
     ]
 

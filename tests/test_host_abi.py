@@ -203,6 +203,24 @@ def test_error_paths(se3):
     assert lib.se3tn_infer(eng._h, C.c_void_p(8), C.c_void_p(8), 1, 0, None, None, None, None, None) == -1
 
 
+def test_trunk_winograd_switch_defaults_and_argument_checks(se3):
+    """se3tn_set/get_trunk_winograd on a host-only context: the defaults are the header's, the ctypes mirror carries the same
+    numbers, bad arguments are refused."""
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "se3tracknet.h")).read()
+    mb = int(re.search(r"#define SE3TN_TRUNK_WINOGRAD_DEFAULT_MIN_BATCH (\d+)", hdr).group(1))
+    mf = int(re.search(r"#define SE3TN_TRUNK_WINOGRAD_DEFAULT_MIN_FILL (\d+)", hdr).group(1))
+    assert (mb, mf) == (se3._lib.TRUNK_WINOGRAD_DEFAULT_MIN_BATCH, se3._lib.TRUNK_WINOGRAD_DEFAULT_MIN_FILL)
+    eng = se3.Engine(device=-1, max_batch=1)
+    assert eng.get_trunk_winograd() == (mb, mf)
+    eng.set_trunk_winograd(0)
+    assert eng.get_trunk_winograd() == (0, mf)
+    eng.set_trunk_winograd(16, 0)
+    assert eng.get_trunk_winograd() == (16, 0)
+    lib = se3._lib.load()
+    assert lib.se3tn_set_trunk_winograd(eng._h, -1, 80) == -1 and lib.se3tn_set_trunk_winograd(eng._h, 8, 101) == -1
+    assert eng.get_trunk_winograd() == (16, 0)
+
+
 def test_model_points_and_object_width(se3, tmp_path):
     rng = np.random.default_rng(1)
     pts = rng.uniform(-0.05, 0.05, (500, 3))
