@@ -49,6 +49,38 @@ __device__ __forceinline__ void at_col(int i, float& a0, float& a1) {
   a1 = i == 0 ? 0.f : (i == 1 ? 1.f : -1.f);
 }
 
+// Vector adds with compile-time signs, as inline asm: (1) asm volatile stays where it is written -- plain C++ adds the compiler sinks
+// below the step's barrier, all of them; (2) the signs ride on the operands' neg modifiers, no extra instruction.
+// (Packed v_pk_add_f32 / v_pk_fma_f32 were measured and dropped: on gfx950 a packed float32 instruction costs exactly two scalar ones,
+// profiles/r03_probe_mfma_valu.txt, and the library stays free of packed-f32 code)
+template <bool NA, bool NB>
+__device__ __forceinline__ float add_pm(const float a, const float b) {   // (+|-) a (+|-) b
+  float r;
+  if constexpr (!NA && !NB) asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  else if constexpr (NA && !NB) asm volatile("v_sub_f32 %0, %2, %1" : "=v"(r) : "v"(a), "v"(b));
+  else if constexpr (!NA && NB) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  else asm volatile("v_sub_f32 %0, -%1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// y += K m for a compile-time K in {0, +1, -1}
+template <int K>
+__device__ __forceinline__ void acc_pm(float& y, const float m) {
+  if constexpr (K > 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(y) : "v"(m));
+  else if constexpr (K < 0) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(y) : "v"(m));
+}
+// the Toom-Cook matrices of F(2x2, 3x3) as compile-time tables
+struct W64Tab {
+  // B^T row i = sgn0 d[r0] + sgn1 d[r1]:  0: d0 - d2;  1: d1 + d2;  2: -d1 + d2;  3: d1 - d3
+  static constexpr int bt_r0(int i) { return i == 0 ? 0 : 1; }
+  static constexpr int bt_r1(int i) { return i == 3 ? 3 : 2; }
+  static constexpr bool bt_n0(int i) { return i == 2; }
+  static constexpr bool bt_n1(int i) { return i == 0 || i == 3; }
+  // A^T = [[1,1,1,0],[0,1,-1,-1]]: entry (row y, column i)
+  static constexpr int at(int y, int i) { return y == 0 ? (i == 3 ? 0 : 1) : (i == 0 ? 0 : (i == 1 ? 1 : -1)); }
+  // float offset inside the LDS patch of window pixel (r, s): LDS column of patch column s is (s >> 1) + 12 (s & 1)
+  static constexpr int off(int r, int s) { return (r * W64_PATCH + (s >> 1) + 12 * (s & 1)) * 32; }
+};
+
 struct Wino64Args {
   const float* in;    // padded NHWC [n][46][46][in_ld], channel offset of group 0 applied
   const float* U;     // group 0: [chunk 2][f 16][cout 64][32]
@@ -151,7 +183,7 @@ __global__ __launch_bounds__(512) void wino64_fused_kernel(const Wino64Args a) {
   const int lo = (hh ^ (X & 1)) * 4, xk = X >> 1;
   const int fo0 = ((0 ^ xk) << 3) + lo, fo1 = ((1 ^ xk) << 3) + lo, fo2 = ((2 ^ xk) << 3) + lo, fo3 = ((3 ^ xk) << 3) + lo;
 
-  float Y[16][4];
+  float Y[16][4];   // Y[e][o]: accumulator element e (cout 8 (e >> 2) + 4 hh + (e & 3)) of output pixel o = 2 y + x of the tile
 #pragma unroll
   for (int e = 0; e < 16; ++e)
 #pragma unroll
@@ -189,15 +221,19 @@ __global__ __launch_bounds__(512) void wino64_fused_kernel(const Wino64Args a) {
 #define W64_MFMA(ACC)                                                                                        \
   ACC = q_ == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[0], pv_[0], zero16, 0, 0, 0)                         \
                 : __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[q_], pv_[q_], ACC, 0, 0, 0);
-#define W64_STEP(S, ACC, PREV)                                                                                  \
+  // One step with the frequency as a compile-time constant: the B^T / A^T entries (0, +-1) become adds / subtracts with neg modifiers
+  // or vanish (36 of the 64 fold terms are non-zero), the window offsets become ds_read immediates, nothing is computed per step.
+#define W64_STEP(F, ACC, PREV)                                                                                  \
   {                                                                                                            \
-    const int s_ = (S), buf = s_ & 1, sn = s_ + 1;                                                             \
-    if (sn < 32) W64_ISSUE_U(sn >> 4, sn & 15, buf ^ 1)                                                         \
-    if (s_ == 15) W64_ISSUE_PATCH(1) /* the patch buffer is free: the transform of step 15 ran during step 14 */ \
+    constexpr int f_ = (F), buf = f_ & 1, fn_ = (f_ + 1) & 15, fp_ = (f_ + 15) & 15;                            \
+    const bool last_ = ch == 1 && f_ == 15;                                                                    \
+    if (!last_) W64_ISSUE_U(f_ == 15 ? 1 : ch, fn_, buf ^ 1)                                                    \
+    if (f_ == 15 && ch == 0) W64_ISSUE_PATCH(1) /* the patch buffer is free: the transform of step 15 ran during step 14 */ \
     {                                                                                                          \
       const float* pP = Vb + buf * W64_V_FLOATS + (rb * 32 + l31) * 32;                                        \
       const float* pW = Ub + buf * W64_U_FLOATS + (cbk * 32 + l31) * 32;                                       \
-      float pv_[16], wv_[16], d_[2][4][4], v_[2][4];                                                           \
+      float pv_[16], wv_[16];                                                                                  \
+      float d_[2][4][4], v_[2][4];   /* [task][window pixel | -][channel] */                                    \
       *reinterpret_cast<float4*>(pv_ + 0) = *reinterpret_cast<const float4*>(pP + fo0);                         \
       *reinterpret_cast<float4*>(wv_ + 0) = *reinterpret_cast<const float4*>(pW + fo0);                         \
       *reinterpret_cast<float4*>(pv_ + 4) = *reinterpret_cast<const float4*>(pP + fo1);                         \
@@ -206,47 +242,51 @@ __global__ __launch_bounds__(512) void wino64_fused_kernel(const Wino64Args a) {
       *reinterpret_cast<float4*>(wv_ + 8) = *reinterpret_cast<const float4*>(pW + fo2);                         \
       *reinterpret_cast<float4*>(pv_ + 12) = *reinterpret_cast<const float4*>(pP + fo3);                        \
       *reinterpret_cast<float4*>(wv_ + 12) = *reinterpret_cast<const float4*>(pW + fo3);                        \
-      W64_BT(sn & 15)   /* (step 15 transforms a patch that is being replaced and step 31 one nobody reads: harmless, branch-free) */ \
-      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                        \
-        *reinterpret_cast<float4*>(d_[j_][0]) = *reinterpret_cast<const float4*>(patch + tpix[j_] + o00_);      \
-        *reinterpret_cast<float4*>(d_[j_][1]) = *reinterpret_cast<const float4*>(patch + tpix[j_] + o01_);      \
-        *reinterpret_cast<float4*>(d_[j_][2]) = *reinterpret_cast<const float4*>(patch + tpix[j_] + o10_);      \
-        *reinterpret_cast<float4*>(d_[j_][3]) = *reinterpret_cast<const float4*>(patch + tpix[j_] + o11_);      \
-      }                                                                                                        \
-      float ay0_, ay1_, ax0_, ax1_;                                                                            \
-      at_col(((s_ + 15) & 15) >> 2, ay0_, ay1_);   /* fold: products of step s - 1 (zeros before step 0) */      \
-      at_col(((s_ + 15) & 15) & 3, ax0_, ax1_);                                                                \
-      const float k00_ = ay0_ * ax0_, k01_ = ay0_ * ax1_, k10_ = ay1_ * ax0_, k11_ = ay1_ * ax1_;              \
+      /* window pixels of frequency fn_ = (i, j): rows bt_r0/1(i), columns bt_r0/1(j) */                        \
+      /* (step 15 of chunk 0 transforms a patch that is being replaced and the last step one nobody reads: harmless, branch-free) */ \
+      constexpr int i_ = fn_ >> 2, j_ = fn_ & 3;                                                               \
+      constexpr int oo_[4] = {W64Tab::off(W64Tab::bt_r0(i_), W64Tab::bt_r0(j_)), W64Tab::off(W64Tab::bt_r0(i_), W64Tab::bt_r1(j_)), \
+                              W64Tab::off(W64Tab::bt_r1(i_), W64Tab::bt_r0(j_)), W64Tab::off(W64Tab::bt_r1(i_), W64Tab::bt_r1(j_))}; \
+      constexpr bool nn_[4] = {W64Tab::bt_n0(i_) != W64Tab::bt_n0(j_), W64Tab::bt_n0(i_) != W64Tab::bt_n1(j_),  \
+                               W64Tab::bt_n1(i_) != W64Tab::bt_n0(j_), W64Tab::bt_n1(i_) != W64Tab::bt_n1(j_)}; \
+      _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                                                          \
+        _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                                                      \
+          *reinterpret_cast<float4*>(d_[t_][w_]) = *reinterpret_cast<const float4*>(patch + tpix[t_] + oo_[w_]); \
+        }                                                                                                      \
+      constexpr int pi_ = fp_ >> 2, pj_ = fp_ & 3;   /* fold: products of the previous step (zeros before the first) */ \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
       _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                       \
-        W64_MFMA(ACC)                                                                                       \
+        W64_MFMA(ACC)                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if (q_ < 8) {   /* first half of the matrix phase: fold (no LDS data needed) */                          \
           _Pragma("unroll") for (int e_ = 2 * q_; e_ < 2 * q_ + 2; ++e_) {                                      \
             const float m_ = PREV[e_];                                                                         \
-            Y[e_][0] += k00_ * m_; Y[e_][1] += k01_ * m_; Y[e_][2] += k10_ * m_; Y[e_][3] += k11_ * m_;        \
-            /* pin the fold here: left alone the compiler sinks all 64 FMAs below the step's barrier */        \
-            asm volatile("" : "+v"(Y[e_][0]), "+v"(Y[e_][1]), "+v"(Y[e_][2]), "+v"(Y[e_][3]));                  \
+            acc_pm<W64Tab::at(0, pi_) * W64Tab::at(0, pj_)>(Y[e_][0], m_);                                     \
+            acc_pm<W64Tab::at(0, pi_) * W64Tab::at(1, pj_)>(Y[e_][1], m_);                                     \
+            acc_pm<W64Tab::at(1, pi_) * W64Tab::at(0, pj_)>(Y[e_][2], m_);                                     \
+            acc_pm<W64Tab::at(1, pi_) * W64Tab::at(1, pj_)>(Y[e_][3], m_);                                     \
           }                                                                                                    \
-        } else {        /* second half: the operand tile of step s + 1 (its window reads have landed by now) */ \
-          const int j_ = (q_ - 8) >> 2, x_ = (q_ - 8) & 3;                                                     \
-          v_[j_][x_] = c00_ * d_[j_][0][x_] + c01_ * d_[j_][1][x_] + c10_ * d_[j_][2][x_] + c11_ * d_[j_][3][x_]; \
-          asm volatile("" : "+v"(v_[j_][x_]));                                                                 \
+        } else {        /* then the operand tile of the next step (its window reads have landed by now) */       \
+          const int t_ = (q_ - 8) >> 2, x_ = (q_ - 8) & 3;                                                     \
+          v_[t_][x_] = add_pm<false, false>(add_pm<nn_[0], nn_[1]>(d_[t_][0][x_], d_[t_][1][x_]),              \
+                                            add_pm<nn_[2], nn_[3]>(d_[t_][2][x_], d_[t_][3][x_]));             \
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
       }                                                                                                        \
       *reinterpret_cast<float4*>(Vb + (buf ^ 1) * W64_V_FLOATS + tdst[0]) = *reinterpret_cast<float4*>(v_[0]); \
       *reinterpret_cast<float4*>(Vb + (buf ^ 1) * W64_V_FLOATS + tdst[1]) = *reinterpret_cast<float4*>(v_[1]); \
     }                                                                                                          \
-    if (sn < 32) wait_dma_and_barrier();                                                                         \
-    if (sn == 16) { /* chunk boundary: the second patch has landed (waited above): only now can its first tile be built */ \
-      W64_TRANSFORM(0, buf ^ 1)                                                                                \
+    if (!last_) wait_dma_and_barrier();                                                                        \
+    if (f_ == 15 && ch == 0) { /* chunk boundary: the second patch has landed (waited above): only now can its first tile be built */ \
+      W64_TRANSFORM(0, 0)                                                                                      \
       __syncthreads();                                                                                         \
     }                                                                                                          \
   }
-  for (int s2 = 0; s2 < 32; s2 += 2) {
-    W64_STEP(s2, accA, accB)
-    W64_STEP(s2 + 1, accB, accA)
+  for (int ch = 0; ch < 2; ++ch) {
+    W64_STEP(0, accA, accB) W64_STEP(1, accB, accA) W64_STEP(2, accA, accB) W64_STEP(3, accB, accA)
+    W64_STEP(4, accA, accB) W64_STEP(5, accB, accA) W64_STEP(6, accA, accB) W64_STEP(7, accB, accA)
+    W64_STEP(8, accA, accB) W64_STEP(9, accB, accA) W64_STEP(10, accA, accB) W64_STEP(11, accB, accA)
+    W64_STEP(12, accA, accB) W64_STEP(13, accB, accA) W64_STEP(14, accA, accB) W64_STEP(15, accB, accA)
   }
   W64_FOLD(accB, 15)    // step 31
 #undef W64_STEP

@@ -6,7 +6,8 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int NV, int NACC, bool MFMA>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NV, int NACC, bool MFMA, int KIND = 0>   // KIND 0: v_fma_f32, 1: v_pk_fma_f32, 2: v_pk_add_f32, 3: v_add_f32
 __global__ __launch_bounds__(512) void k(float* out, int iters) {
   f32x16 acc[NACC];
   for (int c = 0; c < NACC; ++c)
@@ -14,24 +15,31 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
   float a = threadIdx.x * 1e-3f, b = 1.0f + blockIdx.x * 1e-6f;
   float y[8];
   for (int i = 0; i < 8; ++i) y[i] = i;
+  f32x2 y2[8], a2 = {a, a}, b2 = {b, b};
+  for (int i = 0; i < 8; ++i) y2[i] = f32x2{(float)i, (float)i};
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       if (MFMA) acc[q % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q % NACC], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int v = 0; v < NV; ++v) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(y[v & 7]) : "v"(a), "v"(b));
+      for (int v = 0; v < NV; ++v) {
+        if (KIND == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(y[v & 7]) : "v"(a), "v"(b));
+        else if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(y2[v & 7]) : "v"(a2), "v"(b2));
+        else if (KIND == 2) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y2[v & 7]) : "v"(a2));
+        else asm volatile("v_add_f32 %0, %0, %1" : "+v"(y[v & 7]) : "v"(a));
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   float s = 0.f;
   for (int c = 0; c < NACC; ++c)
     for (int e = 0; e < 16; ++e) s += acc[c][e];
-  for (int i = 0; i < 8; ++i) s += y[i];
+  for (int i = 0; i < 8; ++i) s += y[i] + y2[i].x + y2[i].y;
   out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
-template <int NV, int NACC, bool MFMA>
+template <int NV, int NACC, bool MFMA, int KIND = 0>
 void run(const char* name, float* out) {
   const int iters = 4000;
   hipEvent_t e0, e1;
@@ -39,7 +47,7 @@ void run(const char* name, float* out) {
   float best = 1e9f;
   for (int r = 0; r < 3; ++r) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<NV, NACC, MFMA>), dim3(256), dim3(512), 0, 0, out, iters);
+    hipLaunchKernelGGL((k<NV, NACC, MFMA, KIND>), dim3(256), dim3(512), 0, 0, out, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -59,6 +67,13 @@ int main() {
   run<12, 1, true>("MFMA chain + 12 VALU each", out);
   run<16, 1, true>("MFMA chain + 16 VALU each", out);
   run<8, 2, true>("2 MFMA chains + 8 VALU each", out);
+  run<8, 1, true, 1>("MFMA chain + 8 v_pk_fma_f32 each", out);
+  run<8, 1, true, 2>("MFMA chain + 8 v_pk_add_f32 each", out);
+  run<8, 1, true, 3>("MFMA chain + 8 v_add_f32 each", out);
+  run<4, 1, true, 1>("MFMA chain + 4 v_pk_fma_f32 each", out);
+  run<8, 1, false, 1>("8 v_pk_fma_f32 only", out);
+  run<8, 1, false, 2>("8 v_pk_add_f32 only", out);
+  run<8, 1, false, 3>("8 v_add_f32 only", out);
   run<4, 1, false>("4 VALU only", out);
   run<8, 1, false>("8 VALU only", out);
   run<16, 1, false>("16 VALU only", out);
