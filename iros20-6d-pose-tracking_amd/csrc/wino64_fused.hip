@@ -33,7 +33,8 @@ constexpr int W64_V_FLOATS = 128 * 32, W64_U_FLOATS = 64 * 32;
 // grouped launch -- as everywhere in this library the K-loop does not wait for data, it loses issue slots to the DMA)
 constexpr int W64_UBUFS = 2;
 constexpr int W64_LDS_FLOATS = W64_PATCH_FLOATS + 2 * W64_V_FLOATS + W64_UBUFS * W64_U_FLOATS;   // 30,720 floats = 122,880 B
-constexpr size_t W64_LDS_BYTES = sizeof(float) * W64_LDS_FLOATS;
+constexpr int W64_YLDS_FLOATS = W64_TILES * W64_TILES * (4 * 64 + 4);                          // epilogue staging: 31,460 floats = 125,840 B
+constexpr size_t W64_LDS_BYTES = sizeof(float) * (W64_YLDS_FLOATS > W64_LDS_FLOATS ? W64_YLDS_FLOATS : W64_LDS_FLOATS);
 }  // namespace
 
 // B^T row i of F(2x2): two non-zero entries (r0, +-1), (r1, +-1):  i=0: d0 - d2;  1: d1 + d2;  2: -d1 + d2;  3: d1 - d3
@@ -299,29 +300,47 @@ __global__ __launch_bounds__(512) void wino64_fused_kernel(const Wino64Args a) {
 #undef W64_TR_STORE
 #undef W64_BT
 
-  // ---- epilogue: every wave stores its own 32 tiles x 32 couts (bias, residual, ReLU; float4 of 4 couts per store) ----------------
+  // ---- epilogue.  A lane holds tile t x 16 couts x 4 pixels: stored straight from the registers that is 32 contiguous bytes per pixel and
+  // lane pair.  So Y goes through the now idle LDS -- [tile][pixel o][64 couts], tile rows padded to 260 floats so that neighbouring
+  // lanes hit different banks -- and comes back pixel-major: 16 lanes x float4 = the 256 contiguous bytes of one pixel's 64 couts, four
+  // pixels per wave instruction; bias, residual (read the same way) and ReLU on the way out.  (Worth 1-3 us per launch.  The stores
+  // themselves cost 5-14 us per round of workgroups -- knock-out -- because a full round ends at once and writes 32 MB with every CU
+  // idle; a persistent variant that issues the next unit's first DMA before storing measured no better: 0.109 / 0.117 ms either way.)
+  constexpr int YS = 4 * 64 + 4;
+  __syncthreads();   // all operand tiles are consumed
+  {
+    const int t = rb * 32 + l31;
+    if (t < W64_TILES * W64_TILES) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(smem + t * YS + o * 64 + cbk * 32 + q * 8 + hh * 4) =
+              make_float4(Y[4 * q + 0][o], Y[4 * q + 1][o], Y[4 * q + 2][o], Y[4 * q + 3][o]);
+    }
+  }
+  __syncthreads();
   const float* __restrict__ bias = a.bias + (size_t)g * a.bias_gs;
   const float* __restrict__ res = (EPI == 1) ? a.res + (size_t)g * a.res_gs : nullptr;
   float* __restrict__ out = a.out + (size_t)g * a.out_gs;
-  const int t = rb * 32 + l31;
-  if (t < W64_TILES * W64_TILES) {
-    const int ty = t / W64_TILES, tx = t - ty * W64_TILES;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
+  const int c4 = (tid & 15) * 4;
+  const float4 b = *reinterpret_cast<const float4*>(bias + c4);
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int p = (k * 512 + tid) >> 4;          // (tile, pixel) index: 484 of the 512 are real
+    const int t = p >> 2, o = p & 3;
+    if (t < W64_TILES * W64_TILES) {
+      const int ty = t / W64_TILES, tx = t - ty * W64_TILES;
       const int oy = y0 + 2 * ty + (o >> 1) + 1, ox = x0 + 2 * tx + (o & 1) + 1;   // padded coordinates of the output pixel
       const size_t pix = (size_t)(img * HP + oy) * HP + ox;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = cbk * 32 + q * 8 + hh * 4;
-        const float4 b = *reinterpret_cast<const float4*>(bias + c);
-        float4 v = make_float4(Y[4 * q + 0][o] + b.x, Y[4 * q + 1][o] + b.y, Y[4 * q + 2][o] + b.z, Y[4 * q + 3][o] + b.w);
-        if (EPI == 1) {
-          const float4 r = *reinterpret_cast<const float4*>(res + pix * a.res_ld + c);
-          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-        }
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        *reinterpret_cast<float4*>(out + pix * a.out_ld + c) = v;
+      float4 v = *reinterpret_cast<const float4*>(smem + t * YS + o * 64 + c4);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      if (EPI == 1) {
+        const float4 r = *reinterpret_cast<const float4*>(res + pix * a.res_ld + c4);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       }
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      *reinterpret_cast<float4*>(out + pix * a.out_ld + c4) = v;
     }
   }
 }
