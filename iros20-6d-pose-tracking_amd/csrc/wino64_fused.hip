@@ -15,9 +15,12 @@
 //       U_f chunk [64 couts x 32] DMA'd from the pre-transformed weights (U = G g G^T, float64 -> float32 once)   [double-buffered, 2 x 8 KB]
 //       M_f = V_f U_f on v_mfma_f32_32x32x2_f32: 8 waves = 4 row blocks x 2 cout blocks, one 32 x 32 block each
 //       Y[y][x] += A^T[y][i] A^T[x][j] M_f   in registers (A^T entries are 0 / +-1): the 16 M_f never exist at the same time
-//   at the end + bias (+ residual), ReLU, float4 stores of the 2 x 2 outputs per tile.
+//   the step is software-pipelined inside every wave (MFMAs of step s | fold of step s - 1 | operand tile of step s + 1) and the 16
+//   frequencies are unrolled, so that every B^T / A^T entry is a compile-time 0 / +-1: vector work is NOT hidden behind MFMAs on
+//   gfx950 (profiles/r03_probe_mfma_valu.txt), the instruction count of a step is what the kernel's time follows
+//   at the end Y is staged through LDS: + bias (+ residual), ReLU, pixel-major float4 stores of the 2 x 2 outputs per tile.
 //
-// MFMA work: 16 x 2 x (128 x 64 x 32) per tile = 2.25x less than direct (incl. the 7 unused rows).  Float32 throughout; rounding as
+// MFMA work: 16 x 2 x (128 x 64 x 32) MACs per workgroup = 2.13x less than direct (incl. the 7 unused rows).  Float32 throughout; rounding as
 // F(2x2) in wino_mfma.hip (1.5e-7 of the layer's largest activation).  Operand tiles use the same 128-byte rows, XOR swizzle and
 // fragment layout as conv3x3_mfma.hip / wino_mfma.hip.
 #include "mfma_common.h"
