@@ -28,6 +28,7 @@ for mode in ("f32", "f16x3", "direct"):
         pe.set_precision(se3._lib.PREC_F16X3)
     elif mode == "direct":
         pe.set_winograd(0)
+        pe.set_trunk_winograd(0)
     ref = [torch.empty((n, 3), device="cuda"), torch.empty((n, 3), device="cuda"), torch.empty_like(poseA)]
     pe.engines[0].infer(Ac, Bc, n, se3.NCHW, ref[0], ref[1], poseA, ref[2])
     torch.cuda.synchronize()
