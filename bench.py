@@ -664,7 +664,7 @@ class DryEngine:
         return 8, 4
 
     def get_trunk_winograd(self):
-        return 8, 80
+        return 8, 55
 
     def overflow(self):
         return False

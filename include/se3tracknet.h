@@ -113,11 +113,12 @@ int se3tn_get_winograd(const se3tn_ctx* ctx, int* min_batch, int* tile);
  * run its four launches as a FUSED Winograd F(2x2, 3x3) kernel -- input transform, the 16 per-frequency products on the f32 matrix
  * cores and the output transform inside one workgroup per image quadrant, nothing spilled to memory; 2.25x fewer multiplies and
  * exactly 2 / 1 rounds of workgroups on the 256 CUs at batch 64.  A launch takes that kernel when its 4 n groups workgroups fill
- * whole rounds of the device's CUs to >= min_fill_percent (n = 64, 128, ...; the grouped A|B launches also at n = 32); otherwise, and always
+ * rounds of the device's CUs to >= min_fill_percent (n >= 34; the grouped A|B launches from n = 18: measured crossovers,
+ * scripts/trunk_sweep.sh, profiles/r03f_trunk_sweep.txt); otherwise, and always
  * with min_batch = 0, the direct implicit-GEMM kernels run.  Float32 arithmetic in a different association (rounding as tile 2
  * above: the logits move by < 1.1e-6). */
 #define SE3TN_TRUNK_WINOGRAD_DEFAULT_MIN_BATCH 8
-#define SE3TN_TRUNK_WINOGRAD_DEFAULT_MIN_FILL 80   /* percent of the last round of workgroups; 0 = every launch with n >= min_batch */
+#define SE3TN_TRUNK_WINOGRAD_DEFAULT_MIN_FILL 55   /* percent of the last round of workgroups; 0 = every launch with n >= min_batch */
 int se3tn_set_trunk_winograd(se3tn_ctx* ctx, int min_batch, int min_fill_percent);
 int se3tn_get_trunk_winograd(const se3tn_ctx* ctx, int* min_batch, int* min_fill_percent);
 /* trans_normalizer / rot_normalizer of Tracker.__init__ (predict.py:128). */

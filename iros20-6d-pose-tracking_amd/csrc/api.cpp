@@ -250,6 +250,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
   c->L = blob_layout();
   c->SL = split_layout();
   if (const char* e = std::getenv("SE3TN_TRUNK_WINOGRAD")) c->wino64_min_batch = std::atoi(e);   // developer A/B switch
+  if (const char* e = std::getenv("SE3TN_TRUNK_WINOGRAD_FILL")) c->wino64_min_fill = std::atoi(e);   // (scripts/trunk_sweep.sh)
   for (int i = 0; i < 8; ++i) { c->mean[i] = 0.0; c->stdv[i] = 1.0; }
   if (device >= 0) {
     hipDeviceProp_t prop;
@@ -393,9 +394,10 @@ int se3tn_set_winograd(se3tn_ctx* c, int min_batch, int tile) {
   return split_prepare(c, nullptr);
 }
 
-// The fused trunk kernel occupies a CU per workgroup (123 KB of LDS) for ~64 us whatever the batch: it beats the direct kernels when
-// its 4 n groups workgroups fill whole rounds of the CUs (measured, scripts/trunk_sweep.sh: n = 64 -> 2 | 1 rounds, 131 | 66 us vs
-// 155 | 81 us direct; n = 32 grouped 66 vs 81; but n = 48 grouped = 1.5 rounds 124 vs 117, n = 32 single = half a round 63 vs 45).
+// The fused trunk kernel occupies a CU per workgroup (126 KB of LDS) for ~52 us whatever the batch: it beats the direct kernels when
+// its 4 n groups workgroups fill the rounds of the CUs to more than half (measured, scripts/trunk_sweep.sh -> profiles/r03f_trunk_sweep.txt:
+// n = 64 -> 2 | 1 rounds, 108 | 56 us vs 155 | 80 us direct; n = 20 grouped = 0.63 round 53 vs 80; but n = 16 grouped and n = 32 single
+// = half a round 52 vs 45; the direct kernels step from one round of their own tiles to two at n = 17 grouped / n = 34 single).
 static bool wino64_pays(const se3tn_ctx* c, int n, int groups) {
   if (c->wino64_min_batch <= 0 || n < c->wino64_min_batch) return false;
   const long wgs = 4L * n * groups, rounds = (wgs + c->num_cus - 1) / c->num_cus;

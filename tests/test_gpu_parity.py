@@ -232,12 +232,12 @@ def test_fused_trunk_winograd_vs_direct_and_oracle(se3, golden_dir):
     assert torch.equal(eng.debug_buffer("q64", 1)[0], q5[3]), "fused trunk: a pair's result depends on its batch"
     ref5 = O.forward(sd, A5, B5)
     _close("n5 logits", l5, torch.cat([ref5["trans_logit"], ref5["rot_logit"]], 1), 0, NET_TOL)
-    # the default rule: at n = 64 all four trunk launches fill 2 | 1 rounds of the 256 CUs -> fused; at n = 48 (1.5 | 0.75 rounds)
-    # none does; at n = 32 only the grouped A2|B2 launches (one full round)
+    # the default rule (rounds of the 256 CUs at least 55 % full): n = 64 -> 2 | 1 rounds, n = 48 -> 1.5 | 0.75: all four launches;
+    # n = 32 and n = 20: only the grouped A2|B2 launches (1.0 | 0.63 of a round; the single ones are 0.5 | 0.31); n = 16: none
     eng.set_trunk_winograd(se3._lib.TRUNK_WINOGRAD_DEFAULT_MIN_BATCH)
     A64, B64 = Fx.net_inputs(5, 64)
     Ac, Bc = A64.cuda(), B64.cuda()
-    for n, want in ((64, 4), (48, 0), (32, 2), (4, 0)):
+    for n, want in ((64, 4), (48, 4), (32, 2), (20, 2), (16, 0), (4, 0)):
         eng.profile_enable(1)
         m(Ac[:n], Bc[:n], return_feature=False)
         torch.cuda.synchronize()
