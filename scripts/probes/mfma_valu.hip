@@ -39,6 +39,57 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
   out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// Specialised waves: waves 0-3 of a workgroup (one per SIMD) issue only MFMAs, waves 4-7 (the other wave of each SIMD) only VALU work
+// (NV v_fma_f32 per MFMA slot of the partner wave): does the vector work of ONE wave hide behind the matrix work of ANOTHER?
+template <int NV, int WHO>   // WHO: 1 = MFMA waves only (others exit), 2 = VALU waves only, 3 = both
+__global__ __launch_bounds__(512) void ksplit(float* out, int iters) {
+  const int wid = threadIdx.x >> 6;
+  f32x16 acc;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float a = threadIdx.x * 1e-3f, b = 1.0f + blockIdx.x * 1e-6f;
+  float y[8];
+  for (int i = 0; i < 8; ++i) y[i] = i;
+  if (wid < 4) {
+    if (WHO & 1)
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+  } else if (WHO & 2) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(y[v & 7]) : "v"(a), "v"(b));
+      }
+    }
+  }
+  float s = 0.f;
+  for (int e = 0; e < 16; ++e) s += acc[e];
+  for (int i = 0; i < 8; ++i) s += y[i];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+template <int NV, int WHO>
+void run_split(const char* name, float* out) {
+  const int iters = 4000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int r = 0; r < 3; ++r) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((ksplit<NV, WHO>), dim3(256), dim3(512), 0, 0, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  printf("%-60s %8.3f ms   %6.1f clk per slot (one MFMA of the matrix wave + NV VALU of the vector wave)\n", name, best,
+         best * 1e-3 * 2.4e9 / (iters * 16.0));
+}
+
 template <int NV, int NACC, bool MFMA, int KIND = 0>
 void run(const char* name, float* out) {
   const int iters = 4000;
@@ -77,5 +128,13 @@ int main() {
   run<4, 1, false>("4 VALU only", out);
   run<8, 1, false>("8 VALU only", out);
   run<16, 1, false>("16 VALU only", out);
+  printf("\nspecialised waves (per SIMD: one wave issues only MFMAs, the other only v_fma_f32)\n");
+  run_split<16, 1>("matrix waves alone (1 wave per SIMD, MFMA chain)", out);
+  run_split<16, 2>("vector waves alone, 16 VALU per slot", out);
+  run_split<16, 3>("both: matrix waves + vector waves with 16 VALU per slot", out);
+  run_split<8, 2>("vector waves alone, 8 VALU per slot", out);
+  run_split<8, 3>("both: matrix waves + vector waves with 8 VALU per slot", out);
+  run_split<24, 2>("vector waves alone, 24 VALU per slot", out);
+  run_split<24, 3>("both: matrix waves + vector waves with 24 VALU per slot", out);
   return 0;
 }
