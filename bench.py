@@ -522,6 +522,23 @@ def main():
             direct["parity"] = compare_with_oracle(np, parity["_oracle"], trans.cpu().numpy(), rot.cpu().numpy(),
                                                    poseB.cpu().numpy().reshape(nb, 4, 4))
         eng.set_winograd(wino_min, wino_tile)
+        if trunk_fused and wino_on:
+            # third point of the same line: the Winograd blocks as in the headline, the 64-channel trunk on the direct kernels (the
+            # library before the fused trunk kernel): executed flops go UP by the trunk's 2.13 x and so does `frac`, the step gets slower
+            for _ in range(args.warmup):
+                step()
+            eng.profile_enable(sl)
+            dt4 = timed_loop(steps_timed)
+            c4 = float(np.mean([eng.profile_read(s_)[0] for s_ in range(sl)]))
+            eng.profile_enable(0)
+            ex4 = executed_per_pair - sum((2 if "|" in n_ else 1) * (TRUNK_FUSED_FLOP - TRUNK_DIRECT_FLOP) for n_ in trunk_fused)
+            direct["trunk_direct"] = {"algorithm": "Winograd F(%dx%d) blocks as in the headline, 64-channel trunk on the direct kernels "
+                                                   "(se3tn_set_trunk_winograd(ctx, 0))" % (wino_tile, wino_tile),
+                                      "value": round(world * nb * steps_timed / dt4, 1), "unit": "pairs/s",
+                                      "ms_per_step": round(dt4 / steps_timed * 1e3, 4), "conv_ms_per_step": round(c4, 4),
+                                      "flop_per_step_executed": ex4 * nb,
+                                      "achieved": round(ex4 * nb / (c4 * 1e-3) / 1e12, 2),
+                                      "frac": round(ex4 * nb / (c4 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         eng.set_trunk_winograd(trunk_min, trunk_fill)
     assert os.environ.get("SE3TN_NOCHECK") or torch.isfinite(poseB).all()
     assert os.environ.get("SE3TN_NOCHECK") or not eng.overflow(), "f16x3 range guard fired"
