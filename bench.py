@@ -74,7 +74,7 @@ def main():
                          "256/512-channel layers (float32-class error, see DESIGN.md)")
     ap.add_argument("--winograd", type=int, default=None, metavar="MIN_BATCH",
                     help="se3tn_set_winograd threshold (0 = direct kernels only; default: the library's)")
-    ap.add_argument("--winograd-tile", type=int, default=0, choices=[0, 2, 4], help="F(tile x tile,3x3); 0 = library default")
+    ap.add_argument("--winograd-tile", type=int, default=0, choices=[0, 2, 4, 6], help="F(tile x tile,3x3); 0 = library default")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="N > 1: all-gather the poses after every step (overlapped with the next step) instead of once "
                          "at the end of the timed region")
@@ -621,7 +621,7 @@ def main():
             out["alt_precision"] = other
         if direct is not None:
             out["alt_algorithm"] = direct
-        prof = pmc_traffic(nb, wino_on, bool(trunk_fused))
+        prof = pmc_traffic(nb, wino_on, bool(trunk_fused), wino_tile)
         if prof is not None:
             out["roofline"]["traffic_from_profile"] = prof
         if world == 1 and not args.no_cpu_baseline:
@@ -678,7 +678,7 @@ class DryEngine:
         return [("stem7x7_mfma", 0.2), ("convAB1 s2", 0.5), ("trans|rot conv1 s2", 0.5)]
 
     def get_winograd(self):
-        return 8, 4
+        return 8, 6
 
     def get_trunk_winograd(self):
         return 8, 55
@@ -755,7 +755,7 @@ def check_timed_batch(np, torch, se3, O, eng, sd, nb, frames_rgb, frames_d, rend
     return res, (A, B)
 
 
-def pmc_traffic(nb, wino_on, trunk_fused=False):
+def pmc_traffic(nb, wino_on, trunk_fused=False, wino_tile=4):
     """HBM bytes per step of the conv3x3 family from the newest COMMITTED rocprofv3 PMC summary
     (profiles/*_pmc.json: FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, KB, separate passes of this same
     command at batch 64).  NOT measured by this run (PMC needs rocprofv3 around the process): reported as
@@ -771,6 +771,14 @@ def pmc_traffic(nb, wino_on, trunk_fused=False):
     total = 0.0
     wino_calls = {"wino_input_kernel": 2, "wino_gemm_kernel": 2, "wino_output_kernel": 1, "wino_mid_kernel": 1,
                   "wino_tail_kernel": 1, "fc_finish_kernel": 1}
+    gemm_shape = ["1", "4", "3", "1"]          # 96 x 128 tiles (F(4x4) at batch 64)
+    if wino_on and wino_tile != 4:
+        # conv-by-conv form (F(6x6) / F(2x2)): in, GEMM, out per conv; per instantiation: the in-transform runs 4 x (2 per block), the
+        # GEMM 2 x per channel count, the out-transform 2 x per epilogue kind; then the separate tail kernel
+        if not any(k.startswith("wino_input_kernel<%d," % wino_tile) for k in d["fetch"]):
+            return None                          # the committed PMC summary is of another tile: no figure rather than a wrong one
+        wino_calls = {"wino_input_kernel": 4, "wino_gemm_kernel": 2, "wino_output_kernel": 2, "tail_kernel": 1}
+        gemm_shape = ["2", "2", "2", "2"]       # 128 x 128 tiles
     for k, v in d["fetch"].items():
         if k not in d["write"]:
             continue
@@ -784,6 +792,10 @@ def pmc_traffic(nb, wino_on, trunk_fused=False):
                 continue
             if "<" in k:   # the f16x3 instantiations (last template argument SP / MM = 1) belong to the alt_precision leg
                 targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
+                if base in ("wino_input_kernel", "wino_output_kernel") and targs[0] != str(wino_tile):
+                    continue   # the other tile's transforms (alt legs of the profiled run)
+                if base == "wino_gemm_kernel" and targs[1:5] != gemm_shape:
+                    continue
                 nargs = {"wino_input_kernel": 3, "wino_output_kernel": 4, "wino_mid_kernel": 3, "wino_tail_kernel": 3, "wino_gemm_kernel": 6}
                 if len(targs) == nargs.get(base, -1) and targs[-1] == "1":
                     continue

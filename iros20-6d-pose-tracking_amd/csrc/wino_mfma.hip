@@ -58,13 +58,25 @@ __host__ __device__ __forceinline__ constexpr float wino_bt(int i, int j) {  // 
   constexpr float t2[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
   constexpr float t4[6][6] = {{1, -1.5f, -2, 1.5f, 1, 0}, {0, -1, 0.5f, 2.5f, 1, 0}, {0, 1, -2.5f, 0.5f, 1, 0},
                               {0, -2, -1, 2, 1, 0},       {0, 0.5f, -1, -0.5f, 1, 0}, {0, 1, -1.5f, -2, 1.5f, 1}};
-  return M == 2 ? t2[i & 3][j & 3] : t4[i][j];
+  // F(6x6): points {0, 1, -1, 2, -2, 1/2, -1/2, inf} (scripts/study_winograd_rounding.py derives all three tables in exact
+  // rationals and reproduces t4 entry by entry; tests/test_winograd_matrices.py checks the identity on the tables parsed from here)
+  constexpr float t6[8][8] = {{-1, 0, 5.25f, 0, -5.25f, 0, 1, 0},        {0, 1, 1, -4.25f, -4.25f, 1, 1, 0},
+                              {0, -1, 1, 4.25f, -4.25f, -1, 1, 0},       {0, 0.5f, 0.25f, -2.5f, -1.25f, 2, 1, 0},
+                              {0, -0.5f, 0.25f, 2.5f, -1.25f, -2, 1, 0}, {0, 2, 4, -2.5f, -5, 0.5f, 1, 0},
+                              {0, -2, 4, 2.5f, -5, -0.5f, 1, 0},         {0, -1, 0, 5.25f, 0, -5.25f, 0, 1}};
+  return M == 2 ? t2[i & 3][j & 3] : M == 4 ? t4[i % 6][j % 6] : t6[i & 7][j & 7];
 }
 template <int M>
 __host__ __device__ __forceinline__ constexpr float wino_at(int i, int j) {  // A^T [M x (M+2)]
   constexpr float t2[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
   constexpr float t4[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 0.5f, -2, 0}, {0, 1, 1, 0.25f, 4, 0}, {0, 1, -1, 0.125f, -8, 1}};
-  return M == 2 ? t2[i & 1][j & 3] : t4[i][j];
+  constexpr float t6[6][8] = {{1, 1, 1, 1, 1, 1, 1, 0},
+                              {0, 1, -1, 2, -2, 0.5f, -0.5f, 0},
+                              {0, 1, 1, 4, 4, 0.25f, 0.25f, 0},
+                              {0, 1, -1, 8, -8, 0.125f, -0.125f, 0},
+                              {0, 1, 1, 16, 16, 0.0625f, 0.0625f, 0},
+                              {0, 1, -1, 32, -32, 0.03125f, -0.03125f, 1}};
+  return M == 2 ? t2[i & 1][j & 3] : M == 4 ? t4[i & 3][j % 6] : t6[i % 6][j & 7];
 }
 template <int M>
 __host__ __device__ __forceinline__ constexpr double wino_g(int i, int j) {  // G [(M+2) x 3]
@@ -75,7 +87,15 @@ __host__ __device__ __forceinline__ constexpr double wino_g(int i, int j) {  // 
                                {-16.0 / 15, -8.0 / 15, -4.0 / 15},
                                {1.0 / 15, -2.0 / 15, 4.0 / 15},
                                {0, 0, 1}};
-  return M == 2 ? t2[i & 3][j] : t4[i][j];
+  constexpr double t6[8][3] = {{-1, 0, 0},
+                               {-2.0 / 9, -2.0 / 9, -2.0 / 9},
+                               {-2.0 / 9, 2.0 / 9, -2.0 / 9},
+                               {1.0 / 90, 1.0 / 45, 2.0 / 45},
+                               {1.0 / 90, -1.0 / 45, 2.0 / 45},
+                               {32.0 / 45, 16.0 / 45, 8.0 / 45},
+                               {32.0 / 45, -16.0 / 45, 8.0 / 45},
+                               {0, 0, 1}};
+  return M == 2 ? t2[i & 3][j] : M == 4 ? t4[i % 6][j] : t6[i & 7][j];
 }
 
 template <int VEC> struct VecT;
@@ -144,6 +164,35 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoArgs a) {
   const float* __restrict__ src = a.in + (size_t)g * a.in_gs + (SP ? 0 : id.cv * VEC);
   // padded rows M ty .. M ty + M + 1 = input rows M ty - 1 .. M ty + M; windows of the last tile row /
   // column may reach past the border: those entries only feed dropped outputs
+  float bt[N][N][VEC];  // B^T d
+  if constexpr (M == 6) {
+    // 8 x 8 windows: d and B^T d together would be 256 registers per thread at VEC = 2, so the window is read one COLUMN at a time
+    // (the row transform of column s needs column s only); same operations in the same order as the generic form below
+    static_assert(SP == 0, "F(6x6) is a float32 path");
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+      float dc[N][VEC];
+      const int X = M * id.tx + s;
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const int Y = M * id.ty + r;
+        vec v;
+        if (Y < Hp && X < Wp) v = *reinterpret_cast<const vec*>(src + (size_t)((id.n * Hp + Y) * Wp + X) * a.in_ld);
+        else __builtin_memset(&v, 0, sizeof(v));
+        __builtin_memcpy(dc[r], &v, sizeof(v));
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float acc = 0.f;
+          bool first = true;
+#pragma unroll
+          for (int r = 0; r < N; ++r) axpy(acc, wino_bt<M>(i, r), dc[r][e], first);
+          bt[i][s][e] = acc;
+        }
+    }
+  } else {
   float d[N][N][VEC];
 #pragma unroll
   for (int r = 0; r < N; ++r)
@@ -160,7 +209,6 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoArgs a) {
       else __builtin_memset(&v, 0, sizeof(v));
       __builtin_memcpy(d[r][s], &v, sizeof(v));
     }
-  float bt[N][N][VEC];  // B^T d
 #pragma unroll
   for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -173,6 +221,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoArgs a) {
         for (int r = 0; r < N; ++r) axpy(acc, wino_bt<M>(i, r), d[r][s][e], first);
         bt[i][s][e] = acc;
       }
+  }
   float* __restrict__ dst = a.V + ((size_t)g * a.nf * a.T + id.t) * a.C + (SP ? 0 : id.cv * VEC);
   const size_t fs = (size_t)a.T * a.C;  // floats per frequency plane
   bool bad = false;
@@ -804,6 +853,7 @@ hipError_t launch_wino_weights(const float* packed, float* U, int cin, int cout,
   const int total = cin * cout;
   if (m == 2) hipLaunchKernelGGL(wino_weight_kernel<2>, dim3((total + 255) / 256), dim3(256), 0, st, packed, U, cout, total);
   else if (m == 4) hipLaunchKernelGGL(wino_weight_kernel<4>, dim3((total + 255) / 256), dim3(256), 0, st, packed, U, cout, total);
+  else if (m == 6) hipLaunchKernelGGL(wino_weight_kernel<6>, dim3((total + 255) / 256), dim3(256), 0, st, packed, U, cout, total);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -931,6 +981,7 @@ hipError_t launch_wino_conv(const WinoArgs& a, int epi, hipStream_t st) {
   if ((a.C != 256 && a.C != 512) || a.Cout % 128 != 0 || (epi != 0 && epi != 1)) return hipErrorInvalidValue;
   if (a.m == 2 && a.nf == 16) return launch_transformed<2, 4>(a, epi, st);
   if (a.m == 4 && a.nf == 36) return launch_transformed<4, WINO4_VEC>(a, epi, st);
+  if (a.m == 6 && a.nf == 64 && !a.split) return launch_transformed<6, 2>(a, epi, st);
   return hipErrorInvalidValue;
 }
 

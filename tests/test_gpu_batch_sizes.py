@@ -1,6 +1,6 @@
 """GPU: every batch size around the algorithm / tile-shape switch points against the CPU oracle.
-Switch points of se3tn_infer (n pairs): split-K latency kernels below ~200 big-tile workgroups per layer, Winograd F(4x4)
-fused blocks from n >= 6, the fused Winograd F(2x2) trunk kernel per launch from n = 18 (grouped A2|B2 launches) / n = 34 (B3) wherever
+Switch points of se3tn_infer (n pairs): split-K latency kernels below ~200 big-tile workgroups per layer, the Winograd
+blocks (default tile F(6x6) conv by conv; F(4x4) fused blocks as the second parametrisation) from n >= 6, the fused Winograd F(2x2) trunk kernel per launch from n = 18 (grouped A2|B2 launches) / n = 34 (B3) wherever
 the rounds of workgroups are >= 55 % full (of the sizes below: 48..52, 63, 64 and 72 run it in all four trunk launches, 25..31 and
 66..69 in the two grouped ones, 33 and everything up to 17 in none), 256 x 128 stride-2 tiles while they fill 200..256 CUs (n = 50..68 for the heads, 26..67 for convAB1), ragged last
 tiles at every n that is not a multiple of the tile size."""
@@ -16,12 +16,15 @@ from oracle import se3_oracle as O
 SIZES = [1, 2, 3, 5, 6, 7, 9, 13, 17, 25, 26, 27, 31, 33, 48, 49, 50, 52, 63, 64, 66, 67, 68, 69, 72]
 
 
-def test_every_switch_point_vs_oracle():
+@pytest.mark.parametrize("tile", [0, 4], ids=["default tile", "F(4x4) fused blocks"])
+def test_every_switch_point_vs_oracle(tile):
     import se3tracknet_amd as se3
     sd = O.make_state_dict(3)
     m = se3.Se3TrackNet(176, max_batch=72)
     m.load_state_dict(sd)
     m.cuda(0)
+    if tile:
+        m.engine.set_winograd(m.engine.get_winograd()[0], tile)
     A, B = Fx.net_inputs(77, 72)
     Ac, Bc = A.cuda(), B.cuda()
     idx = [0, 35, 71]

@@ -140,7 +140,7 @@ def test_batch64_rows_equal_batch1_and_ragged_tail(se3, model0):
     _close("b64 rot", r64[[3, 40]].cpu(), ref["rot"], 0, NET_TOL)
 
 
-@pytest.mark.parametrize("tile", [2, 4])
+@pytest.mark.parametrize("tile", [2, 4, 6])
 def test_winograd_path_vs_direct_and_oracle(se3, golden_dir, tile):
     """The large-batch algorithm of the 256/512-channel residual blocks (Winograd F(tile x tile,3x3),
     float32) forced on at small n: every stage against the oracle and the reference-made golden, and
@@ -164,7 +164,7 @@ def test_winograd_path_vs_direct_and_oracle(se3, golden_dir, tile):
     feat_w, head_w = ow["feature"].cpu(), _nchw(eng.debug_buffer("head", 3), 1)   # _nchw: borders still zero
     lg_w = eng.logits(3).cpu()
     assert not torch.equal(head_w, head_d), "the Winograd path did not run"
-    WINO_SCALE = 2e-5 if tile == 2 else 6e-5   # transform-amplified f32 rounding, relative to the layer's largest activation
+    WINO_SCALE = {2: 2e-5, 4: 6e-5, 6: 1.5e-4}[tile]   # transform-amplified f32 rounding, relative to the layer's largest activation
     _close("feature", feat_w, ref["feature"], ACT_RTOL, 0, WINO_SCALE)
     _close("trans_conv2", head_w[:, :512], ref["trans_c2"], ACT_RTOL, 0, WINO_SCALE)
     _close("rot_conv2", head_w[:, 512:], ref["rot_c2"], ACT_RTOL, 0, WINO_SCALE)
@@ -252,7 +252,7 @@ def _modes(se3, eng):
     wmin, wtile = eng.get_winograd()
     tw = eng.get_trunk_winograd()
     return [
-        ("f32 default (Winograd F(4x4) blocks from n >= %d, fused F(2x2) trunk in full rounds)" % wmin, lambda: None, lambda: None),
+        ("f32 default (Winograd F(%dx%d) blocks from n >= %d, fused F(2x2) trunk in full rounds)" % (wtile, wtile, wmin), lambda: None, lambda: None),
         ("f32 direct kernels only", lambda: (eng.set_winograd(0), eng.set_trunk_winograd(0)),
          lambda: (eng.set_winograd(wmin, wtile), eng.set_trunk_winograd(*tw))),
         ("f16x3", lambda: eng.set_precision(se3._lib.PREC_F16X3), lambda: eng.set_precision(se3._lib.PREC_F32)),
@@ -335,6 +335,8 @@ def test_fused_winograd_blocks_keep_intermediates_is_bit_neutral(se3, model0):
     (F(2x2) selects it) would have left within Winograd rounding, and the zero borders stay zero."""
     model, sd = model0
     eng = model.engine
+    wmin, wtile = eng.get_winograd()
+    eng.set_winograd(wmin, 4)              # the fused blocks are the F(4x4) form (the default tile may be another)
     A, B = Fx.net_inputs(23, 16)
     Ac, Bc = A.cuda(), B.cuda()
     o0 = model(Ac, Bc)
@@ -357,6 +359,7 @@ def test_fused_winograd_blocks_keep_intermediates_is_bit_neutral(se3, model0):
         _close("logits from kept head", l0.cpu(), lg, 0, 2e-6)
     finally:
         eng.keep_intermediates(False)
+        eng.set_winograd(wmin, wtile)
 
 
 def test_batch_permutation_equivariance_bitwise(se3, model0):
@@ -471,8 +474,13 @@ def test_f16x3_mode_parity_and_overflow_guard(se3, model0):
     eng = model.engine
     A, B = Fx.net_inputs(17, 64)
     Ac, Bc = A.cuda(), B.cuda()
+    # the float32 side of every comparison below runs the DIRECT kernels: this test is about the two arithmetic modes, the Winograd
+    # tiles' own rounding (F(6x6): 6e-6 of a feature map's largest value) is test_winograd_path_vs_direct_and_oracle's subject
+    wmin, wtile = eng.get_winograd()
+    eng.set_winograd(0)
     o32 = model(Ac, Bc)
     t32, r32, l32, f32 = o32["trans"].clone(), o32["rot"].clone(), eng.logits(64).clone(), o32["feature"].clone()
+    eng.set_winograd(wmin, wtile)
     eng.set_precision(se3._lib.PREC_F16X3)
     eng.keep_intermediates(True)      # batch 64 runs the fused Winograd blocks also in this mode: "head" is only stored on request
     try:
@@ -495,8 +503,10 @@ def test_f16x3_mode_parity_and_overflow_guard(se3, model0):
         # small batches take the split-K kernels, also on the f16 matrix cores in this mode
         for nn in (1, 4, 20):
             eng.set_precision(se3._lib.PREC_F32)
+            eng.set_winograd(0)
             a = model(Ac[:nn], Bc[:nn])
             a_t, a_f = a["trans"].clone(), a["feature"].clone()
+            eng.set_winograd(wmin, wtile)
             eng.set_precision(se3._lib.PREC_F16X3)
             b = model(Ac[:nn], Bc[:nn])
             assert float((a_t - b["trans"]).abs().max()) < 2e-6, nn
@@ -509,6 +519,7 @@ def test_f16x3_mode_parity_and_overflow_guard(se3, model0):
     finally:
         eng.keep_intermediates(False)
         eng.set_precision(se3._lib.PREC_F32)
+        eng.set_winograd(wmin, wtile)
 
 
 def test_f16x3_split_panels_derived_on_device_equal_host_statement(se3):
@@ -567,11 +578,12 @@ def test_f16x3_numerics_under_awkward_scales(se3, seed):
     m.load_state_dict(sd); m.cuda(0)
     eng = m.engine
     m(A.cuda(), B.cuda(), return_feature=False)
-    l32 = eng.logits(n).clone()              # float32, default algorithms: n = 32 -> Winograd F(4x4) blocks
+    l32 = eng.logits(n).clone()              # float32, default algorithms: n = 32 -> Winograd blocks (the default tile)
+    wmin, wtile = eng.get_winograd()
     eng.set_winograd(0)
     m(A.cuda(), B.cuda(), return_feature=False)
     l32d = eng.logits(n).clone()             # float32, direct kernels only
-    eng.set_winograd(6, 4)
+    eng.set_winograd(wmin, wtile)
     assert not torch.equal(l32, l32d)
     eng.set_precision(se3._lib.PREC_F16X3)
     m(A.cuda(), B.cuda(), return_feature=False)

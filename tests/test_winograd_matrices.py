@@ -1,6 +1,6 @@
 """CPU: the Toom-Cook matrices compiled into wino_mfma.hip (parsed from the source) satisfy the
 Winograd identity  Y = A^T [(G g G^T) (.) (B^T d B)] A  ==  valid 3x3 cross-correlation of the
-(m+2)x(m+2) tile d with g, for m = 2 and m = 4 -- and the float32 rounding of the transformed
+(m+2)x(m+2) tile d with g, for m = 2, 4 and 6 -- and the float32 rounding of the transformed
 algorithm stays in the class DESIGN.md quotes (rms error relative to the largest output)."""
 import os
 import re
@@ -28,10 +28,11 @@ def _matrix(src, func, name):
 def mats():
     src = open(SRC).read()
     return {2: (_matrix(src, "wino_bt", "t2"), _matrix(src, "wino_g", "t2"), _matrix(src, "wino_at", "t2")),
-            4: (_matrix(src, "wino_bt", "t4"), _matrix(src, "wino_g", "t4"), _matrix(src, "wino_at", "t4"))}
+            4: (_matrix(src, "wino_bt", "t4"), _matrix(src, "wino_g", "t4"), _matrix(src, "wino_at", "t4")),
+            6: (_matrix(src, "wino_bt", "t6"), _matrix(src, "wino_g", "t6"), _matrix(src, "wino_at", "t6"))}
 
 
-@pytest.mark.parametrize("m", [2, 4])
+@pytest.mark.parametrize("m", [2, 4, 6])
 def test_identity_in_float64(mats, m):
     BT, G, AT = mats[m]
     n = m + 2
@@ -42,10 +43,10 @@ def test_identity_in_float64(mats, m):
         g = rng.normal(size=(3, 3))
         y = AT @ ((G @ g @ G.T) * (BT @ d @ BT.T)) @ AT.T
         ref = np.array([[np.sum(d[i:i + 3, j:j + 3] * g) for j in range(m)] for i in range(m)])
-        assert np.abs(y - ref).max() < 1e-12
+        assert np.abs(y - ref).max() < (1e-12 if m < 6 else 2e-11)   # the F(6x6) transforms amplify float64 rounding too
 
 
-@pytest.mark.parametrize("m,bound", [(2, 5e-7), (4, 2e-6)])
+@pytest.mark.parametrize("m,bound", [(2, 5e-7), (4, 2e-6), (6, 5e-6)])
 def test_float32_rounding_class(mats, m, bound):
     """One 512-channel layer in float32 (U, V rounded once, products accumulated in float32, transforms
     in float32) against float64: rms error / max |output|."""
