@@ -74,7 +74,8 @@ def main():
                          "256/512-channel layers (float32-class error, see DESIGN.md)")
     ap.add_argument("--winograd", type=int, default=None, metavar="MIN_BATCH",
                     help="se3tn_set_winograd threshold (0 = direct kernels only; default: the library's)")
-    ap.add_argument("--winograd-tile", type=int, default=0, choices=[0, 2, 4, 6], help="F(tile x tile,3x3); 0 = library default")
+    ap.add_argument("--winograd-tile", type=int, default=0, choices=[0, 2, 4, 6, 46],
+                    help="F(tile x tile,3x3); 46 = SE3TN_WINOGRAD_TILE_AUTO (4 below 14 pairs, 6 from there); 0 = library default")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="N > 1: all-gather the poses after every step (overlapped with the next step) instead of once "
                          "at the end of the timed region")
@@ -382,7 +383,9 @@ def main():
     algorithmic = CONV3_FLOP_PER_PAIR * nb / (conv_ms_avg * 1e-3) / 1e12
     # MFMA flops the conv family actually executes: the Winograd layers do (tile+2)^2 multiplies per
     # tile x tile outputs (incl. the rows / columns computed past the map edge) instead of 9 per output
-    wino_min, wino_tile = eng.get_winograd()
+    wino_min, wino_tile_sel = eng.get_winograd()
+    # SE3TN_WINOGRAD_TILE_AUTO (the default): F(4x4) fused blocks below SE3TN_WINOGRAD_TILE6_MIN_BATCH pairs, F(6x6) from there
+    wino_tile = wino_tile_sel if wino_tile_sel != se3._lib.WINOGRAD_TILE_AUTO else (6 if nb >= se3._lib.WINOGRAD_TILE6_MIN_BATCH else 4)
     wino_on = args.precision == "f32" and wino_min > 0 and nb >= wino_min
     executed_per_pair = CONV3_FLOP_PER_PAIR
     if wino_on:
@@ -521,7 +524,7 @@ def main():
         if parity is not None:
             direct["parity"] = compare_with_oracle(np, parity["_oracle"], trans.cpu().numpy(), rot.cpu().numpy(),
                                                    poseB.cpu().numpy().reshape(nb, 4, 4))
-        eng.set_winograd(wino_min, wino_tile)
+        eng.set_winograd(wino_min, wino_tile_sel)
         if trunk_fused and wino_on:
             # third point of the same line: the Winograd blocks as in the headline, the 64-channel trunk on the direct kernels (the
             # library before the fused trunk kernel): executed flops go UP by the trunk's 2.13 x and so does `frac`, the step gets slower
@@ -678,7 +681,7 @@ class DryEngine:
         return [("stem7x7_mfma", 0.2), ("convAB1 s2", 0.5), ("trans|rot conv1 s2", 0.5)]
 
     def get_winograd(self):
-        return 8, 6
+        return 8, 46
 
     def get_trunk_winograd(self):
         return 8, 55

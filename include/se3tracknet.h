@@ -99,7 +99,7 @@ size_t se3tn_split_weights_bytes(const se3tn_ctx* ctx);
 const void* se3tn_split_weights_device(const se3tn_ctx* ctx);
 int se3tn_split_weights_host(const void* packed_blob_host, size_t blob_bytes, void* out_split, size_t out_bytes);
 /* Algorithm of the stride-1 256/512-channel convolutions (AB2.*, trans|rot conv2.*) in
- * SE3TN_PREC_F32: batches of n >= min_batch pairs run them as Winograd F(tile x tile, 3x3), tile = 2 | 4 | 6
+ * SE3TN_PREC_F32: batches of n >= min_batch pairs run them as Winograd F(tile x tile, 3x3), tile = 2 | 4 | 6 | AUTO
  * (0 keeps the current tile) -- float32 MFMA GEMMs on (tile+2)^2 transformed planes, 2.25x / 4x / 5.06x fewer
  * multiplies per output; smaller batches and min_batch = 0 use the direct implicit-GEMM kernels.
  * All are float32 arithmetic and differ by rounding only (rms error of one layer relative to its
@@ -107,9 +107,12 @@ int se3tn_split_weights_host(const void* packed_blob_host, size_t blob_bytes, vo
  * 0.5 / 0.6 / 1.4e-6 against the direct kernels) -- the same freedom cuDNN takes under
  * torch.backends.cudnn.benchmark = True in the reference (predict.py:78).  Tile 4 runs a whole residual block as one
  * fused launch sequence; tile 6 (64 planes: at batch 64 exactly two 128 x 128 GEMM tiles per workgroup slot, 21 % fewer
- * multiplies than tile 4) runs conv by conv.  SE3TN_PREC_F16X3 has F(4x4) only and uses it while tile 6 is selected. */
+ * multiplies than tile 4) runs conv by conv and pays from 14 pairs on.  SE3TN_WINOGRAD_TILE_AUTO (the default) = tile 4 below
+ * SE3TN_WINOGRAD_TILE6_MIN_BATCH pairs, tile 6 from there.  SE3TN_PREC_F16X3 has F(4x4) only and uses it whatever is selected. */
+#define SE3TN_WINOGRAD_TILE_AUTO 46
+#define SE3TN_WINOGRAD_TILE6_MIN_BATCH 14
 #define SE3TN_WINOGRAD_DEFAULT_MIN_BATCH 6
-#define SE3TN_WINOGRAD_DEFAULT_TILE 6
+#define SE3TN_WINOGRAD_DEFAULT_TILE SE3TN_WINOGRAD_TILE_AUTO
 int se3tn_set_winograd(se3tn_ctx* ctx, int min_batch, int tile);
 int se3tn_get_winograd(const se3tn_ctx* ctx, int* min_batch, int* tile);
 /* Algorithm of the 64-channel trunk (convA2 / convB2 / convB3, 44 x 44 maps) in SE3TN_PREC_F32: batches of n >= min_batch pairs MAY

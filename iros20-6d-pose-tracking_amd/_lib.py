@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SE3TN_LIB") or os.path.join(_HERE, "libse3tracknet.so
 
 NCHW, NHWC = 0, 1
 PREC_F32, PREC_F16X3 = 0, 1
+WINOGRAD_TILE_AUTO, WINOGRAD_TILE6_MIN_BATCH = 46, 14   # as include/se3tracknet.h: F(4x4) below 14 pairs, F(6x6) from there
 TRUNK_WINOGRAD_DEFAULT_MIN_BATCH, TRUNK_WINOGRAD_DEFAULT_MIN_FILL = 8, 55   # as include/se3tracknet.h (tests/test_host_abi.py)
 BLUR_NONE, BLUR_BILATERAL, BLUR_GAUSSIAN = 0, 1, 2
 RES = 176

@@ -68,9 +68,11 @@ struct se3tn_ctx {
   size_t part_bytes = 0;
   // Winograd F(m x m,3x3) path (wino_mfma.hip) of convAB2.* and trans|rot conv2.* at n >= wino_min_batch
   int wino_min_batch = SE3TN_WINOGRAD_DEFAULT_MIN_BATCH;  // 0 = never
-  int wino_tile = SE3TN_WINOGRAD_DEFAULT_TILE;            // m = 2 | 4 | 6
+  int wino_tile = SE3TN_WINOGRAD_DEFAULT_TILE;            // m = 2 | 4 | 6 | SE3TN_WINOGRAD_TILE_AUTO
   int wino_tile_derived = 0;                              // the m wino_u was derived for
-  float* wino_u[4] = {nullptr, nullptr, nullptr, nullptr};  // U = G g G^T of LAB2_1, LAB2_2, LH2_1, LH2_2
+  float* wino_u[4] = {nullptr, nullptr, nullptr, nullptr};  // U = G g G^T of LAB2_1, LAB2_2, LH2_1, LH2_2 (tile 2 | 4: wino_tile_derived)
+  float* wino_u6[4] = {nullptr, nullptr, nullptr, nullptr}; // the F(6x6) planes of the same four convs (tile 6 | AUTO only)
+  const float* wino6_blob = nullptr;                        // the blob wino_u6 was derived from
   float *wino_v = nullptr, *wino_m = nullptr;   // [g][16][T][C] input tiles / per-frequency products
   const float* wino_blob = nullptr;             // the blob wino_u was derived from
   // fused F(2x2) path of the 64-channel trunk (wino64_fused.hip) at n >= wino64_min_batch (0 = never)
@@ -138,9 +140,17 @@ static size_t wino_ws_floats(int max_batch) {
   const size_t head = (size_t)16 * 36 * 1024, ab = (size_t)16 * 121 * 256;
   return (size_t)max_batch * (head > ab ? head : ab);
 }
-// The tile the 256 / 512-channel blocks run with: F(6x6) exists in float32 only, so SE3TN_PREC_F16X3 uses F(4x4) (its fused head
-// block on split operands) while tile 6 is selected; U follows at se3tn_set_precision (init time, as every derivation).
-static int eff_tile(const se3tn_ctx* c) { return (c->prec == SE3TN_PREC_F16X3 && c->wino_tile == 6) ? 4 : c->wino_tile; }
+// The tile the 256 / 512-channel blocks of a batch of n pairs run with.  F(6x6) exists in float32 only (SE3TN_PREC_F16X3 keeps F(4x4)
+// and its fused head block on split operands) and pays from 14 pairs on (scripts/tile_sweep.sh: 0.511 vs 0.462 ms at n = 6, 0.701 vs
+// 0.718 at n = 16, 1.76 vs 1.86 at n = 64): SE3TN_WINOGRAD_TILE_AUTO switches there.  With tile 6 | AUTO selected both U sets are
+// resident: the F(4x4) planes in wino_u, the F(6x6) planes in wino_u6.
+static int tile_for(const se3tn_ctx* c, int n) {
+  const int t = c->wino_tile;
+  if (t == 2 || t == 4) return t;
+  if (c->prec == SE3TN_PREC_F16X3) return 4;
+  if (t == 6) return 6;
+  return n >= SE3TN_WINOGRAD_TILE6_MIN_BATCH ? 6 : 4;
+}
 static const ConvId kWino64Convs[4] = {L64_1, L64_2, L64_3, L64_4};
 static int wino64_prepare(se3tn_ctx* c, hipStream_t st) {
   if (c->wino64_min_batch <= 0 || c->max_batch < c->wino64_min_batch || !c->blob || c->wino64_blob == c->blob) return SE3TN_OK;
@@ -165,10 +175,21 @@ static int wino_prepare(se3tn_ctx* c, hipStream_t st) {
     HIPCHK(hipMalloc((void**)&c->wino_m, wino_ws_floats(c->max_batch) * sizeof(float)));
     for (int i = 0; i < 4; ++i) {
       const Conv3& s = conv_specs()[kWinoConvs[i]];
-      HIPCHK(hipMalloc((void**)&c->wino_u[i], (size_t)s.groups * 64 * s.cin * s.cout * sizeof(float)));   // up to F(6x6): 64 planes
+      HIPCHK(hipMalloc((void**)&c->wino_u[i], (size_t)s.groups * 36 * s.cin * s.cout * sizeof(float)));
     }
   }
-  const int tile = eff_tile(c);
+  const int tile = c->wino_tile == 2 ? 2 : 4;   // the planes in wino_u (tile 6 | AUTO keep the F(4x4) set there as well)
+  if (c->blob && (c->wino_tile == 6 || c->wino_tile == SE3TN_WINOGRAD_TILE_AUTO) && c->wino6_blob != c->blob) {
+    for (int i = 0; i < 4; ++i) {
+      const Conv3& s = conv_specs()[kWinoConvs[i]];
+      if (!c->wino_u6[i]) HIPCHK(hipMalloc((void**)&c->wino_u6[i], (size_t)s.groups * 64 * s.cin * s.cout * sizeof(float)));
+      for (int g = 0; g < s.groups; ++g)
+        HIPCHK(launch_wino_weights(c->blob + c->L.conv_w[kWinoConvs[i]] + (size_t)g * conv3_words(s.cin, s.cout),
+                                   c->wino_u6[i] + (size_t)g * 64 * s.cin * s.cout, s.cin, s.cout, 6, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));  // init-time
+    c->wino6_blob = c->blob;
+  }
   if (c->blob && (c->wino_blob != c->blob || c->wino_tile_derived != tile)) {
     const bool new_blob = c->wino_blob != c->blob;
     const int nf = (tile + 2) * (tile + 2);
@@ -310,7 +331,7 @@ void se3tn_destroy(se3tn_ctx* c) {
   if (c->device >= 0) {
     float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
                      c->head_t, c->head_f, c->logits, c->fcpart, c->part, c->blob_owned, c->split_w, c->wino_v, c->wino_m,
-                     c->wino_u[0], c->wino_u[1], c->wino_u[2], c->wino_u[3],
+                     c->wino_u[0], c->wino_u[1], c->wino_u[2], c->wino_u[3], c->wino_u6[0], c->wino_u6[1], c->wino_u6[2], c->wino_u6[3],
                      c->wino_us[0], c->wino_us[1], c->wino_us[2], c->wino_us[3], c->wino_usc[0], c->wino_usc[1], c->wino_usc[2],
                      c->wino_usc[3], c->wino64_u[0], c->wino64_u[1], c->wino64_u[2], c->wino64_u[3]};
     for (float* b : bufs)
@@ -391,8 +412,8 @@ int se3tn_bind_weights(se3tn_ctx* c, const void* device_blob, size_t bytes) {
 }
 
 int se3tn_set_winograd(se3tn_ctx* c, int min_batch, int tile) {
-  if (!c || min_batch < 0 || (tile != 0 && tile != 2 && tile != 4 && tile != 6))
-    return fail(SE3TN_E_ARG, "se3tn_set_winograd: min_batch >= 0 and tile in {0, 2, 4, 6}");
+  if (!c || min_batch < 0 || (tile != 0 && tile != 2 && tile != 4 && tile != 6 && tile != SE3TN_WINOGRAD_TILE_AUTO))
+    return fail(SE3TN_E_ARG, "se3tn_set_winograd: min_batch >= 0 and tile in {0, 2, 4, 6, SE3TN_WINOGRAD_TILE_AUTO}");
   c->wino_min_batch = min_batch;
   if (tile) c->wino_tile = tile;
   if (c->device < 0) return SE3TN_OK;
@@ -444,8 +465,8 @@ int se3tn_set_normalization(se3tn_ctx* c, const double mean[8], const double std
 int se3tn_set_precision(se3tn_ctx* c, int mode) {
   if (!c || (mode != SE3TN_PREC_F32 && mode != SE3TN_PREC_F16X3)) return fail(SE3TN_E_ARG, "se3tn_set_precision: bad mode");
   c->prec = mode;
-  // first selection of f16x3 (or new weights since): derive the split panels from the bound blob -- here, not in se3tn_infer;
-  // U first: with tile 6 selected the two precisions use different Winograd tiles (eff_tile)
+  // first selection of f16x3 (or new weights since): derive the split panels from the bound blob -- here, not in se3tn_infer
+  // (after U: the split rows of the F(4x4) planes come from wino_u)
   if (c->device >= 0) {
     if (int rc = wino_prepare(c, nullptr)) return rc;
   }
@@ -651,12 +672,14 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
                   float* out, int out_ld, int out_gs, int hin, int stride, int epi, const char* name) -> int {
     const Conv3& s = conv_specs()[id];
     const int ws = wino_slot(id);
-    if (ws >= 0 && !fast && c->wino_min_batch > 0 && n >= c->wino_min_batch && c->wino_v && c->wino_tile_derived == eff_tile(c)) {
+    const int wtile = tile_for(c, n);
+    const bool u_ready = wtile == 6 ? (c->wino_u6[0] && c->wino6_blob == c->blob) : (c->wino_tile_derived == wtile);
+    if (ws >= 0 && !fast && c->wino_min_batch > 0 && n >= c->wino_min_batch && c->wino_v && u_ready) {
       WinoArgs w{};
-      w.in = in; w.U = c->wino_u[ws]; w.bias = W + L.conv_b[id]; w.res = res; w.out = out;
+      w.in = in; w.U = wtile == 6 ? c->wino_u6[ws] : c->wino_u[ws]; w.bias = W + L.conv_b[id]; w.res = res; w.out = out;
       w.V = c->wino_v; w.Mw = c->wino_m;
       w.in_ld = in_ld; w.res_ld = res_ld; w.out_ld = out_ld;
-      w.m = eff_tile(c); w.nf = (w.m + 2) * (w.m + 2);
+      w.m = wtile; w.nf = (w.m + 2) * (w.m + 2);
       w.H = hin; w.W = hin; w.th = (hin + w.m - 1) / w.m; w.tw = w.th;
       w.n = n; w.T = n * w.th * w.tw;
       w.C = s.cin; w.Cout = s.cout; w.groups = s.groups;
@@ -703,7 +726,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
   // ResnetBasicBlocks of 256 / 512 channels: at n >= wino_min_batch with F(4x4) the whole block runs through
   // launch_wino_block (conv1's out-transform fused with conv2's in-transform; the heads' last out-transform fused
   // with avg-pool + FC + tanh); otherwise conv by conv (direct / split-K / F(2x2) kernels)
-  const bool wino_block = c->wino_min_batch > 0 && n >= c->wino_min_batch && c->wino_v && eff_tile(c) == 4 && c->wino_tile_derived == 4 &&
+  const bool wino_block = c->wino_min_batch > 0 && n >= c->wino_min_batch && c->wino_v && tile_for(c, n) == 4 && c->wino_tile_derived == 4 &&
                           (!fast || (c->wino_us_blob == c->blob && c->wino_us_tile == 4));
   struct MarkCtx { se3tn_ctx* c; hipStream_t st; const char* name; };
   auto mark_fn = [](void* p) -> int { MarkCtx* m = (MarkCtx*)p; return prof_mark(m->c, m->st, m->name, true); };

@@ -135,7 +135,8 @@ class Engine:
 
     def set_winograd(self, min_batch, tile=0):
         """Batches of n >= min_batch run the 256/512-channel stride-1 convs as Winograd F(tile x tile,3x3)
-        (float32; tile 2 | 4 | 6, 0 = keep); min_batch 0 = always the direct kernels.  Defaults:
+        (float32; tile 2 | 4 | 6 | _lib.WINOGRAD_TILE_AUTO = 4 below 14 pairs, 6 from there; 0 = keep); min_batch 0 = always the direct
+        kernels.  Defaults:
         SE3TN_WINOGRAD_DEFAULT_MIN_BATCH / _TILE of include/se3tracknet.h."""
         check(self.lib.se3tn_set_winograd(self._h, int(min_batch), int(tile)), "se3tn_set_winograd")
 

@@ -1,6 +1,7 @@
 """GPU: every batch size around the algorithm / tile-shape switch points against the CPU oracle.
 Switch points of se3tn_infer (n pairs): split-K latency kernels below ~200 big-tile workgroups per layer, the Winograd
-blocks (default tile F(6x6) conv by conv; F(4x4) fused blocks as the second parametrisation) from n >= 6, the fused Winograd F(2x2) trunk kernel per launch from n = 18 (grouped A2|B2 launches) / n = 34 (B3) wherever
+blocks (default: F(4x4) fused blocks for 6 <= n < 14, F(6x6) conv by conv from n = 14; F(4x4) at every n as the second
+parametrisation) from n >= 6, the fused Winograd F(2x2) trunk kernel per launch from n = 18 (grouped A2|B2 launches) / n = 34 (B3) wherever
 the rounds of workgroups are >= 55 % full (of the sizes below: 48..52, 63, 64 and 72 run it in all four trunk launches, 25..31 and
 66..69 in the two grouped ones, 33 and everything up to 17 in none), 256 x 128 stride-2 tiles while they fill 200..256 CUs (n = 50..68 for the heads, 26..67 for convAB1), ragged last
 tiles at every n that is not a multiple of the tile size."""

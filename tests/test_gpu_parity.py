@@ -252,7 +252,8 @@ def _modes(se3, eng):
     wmin, wtile = eng.get_winograd()
     tw = eng.get_trunk_winograd()
     return [
-        ("f32 default (Winograd F(%dx%d) blocks from n >= %d, fused F(2x2) trunk in full rounds)" % (wtile, wtile, wmin), lambda: None, lambda: None),
+        ("f32 default (Winograd blocks from n >= %d, tile %s, fused F(2x2) trunk in full rounds)"
+         % (wmin, "4 | 6 by batch size" if wtile == se3._lib.WINOGRAD_TILE_AUTO else wtile), lambda: None, lambda: None),
         ("f32 direct kernels only", lambda: (eng.set_winograd(0), eng.set_trunk_winograd(0)),
          lambda: (eng.set_winograd(wmin, wtile), eng.set_trunk_winograd(*tw))),
         ("f16x3", lambda: eng.set_precision(se3._lib.PREC_F16X3), lambda: eng.set_precision(se3._lib.PREC_F32)),
