@@ -24,37 +24,31 @@ from oracle import se3_oracle as O
 
 
 def toom_cook(m, points):
-    """A^T [m x n], G [n x 3], B^T [n x n] (n = m + 2) for F(m, 3) from n - 1 finite points + infinity, exact rationals.
-    Construction: Y = A^T [(G g) (.) (B^T d)] with A^T / G the Vandermonde evaluation matrices of the output / filter
-    polynomials and B^T from the inverse transposed Vandermonde of degree n - 1 (Lavin & Gray, via the transposition principle)."""
+    """A^T [m x n], G [n x 3], B^T [n x n] (n = m + 2) for F(m, 3) from n - 1 finite points + the point at infinity, in exact
+    rationals (Toom-Cook / Lavin & Gray):  Y = A^T [(G g) (.) (B^T d)].
+      A^T = transposed Vandermonde matrix of the points for polynomials of degree m - 1 (last column: infinity -> leading coefficient);
+      G   = Vandermonde rows for degree 2, row i divided by N_i = prod_{k != i}(p_i - p_k)  (the Lagrange normalisation);
+      B^T = row i: coefficients of prod_{k != i}(x - p_k);  last row: prod_k (x - p_k)."""
     n = m + 2
     pts = [Fraction(p) for p in points]
     assert len(pts) == n - 1
-    # evaluation matrices (last row = point at infinity: leading coefficient)
+
     def vander(cols):
         rows = [[p ** j for j in range(cols)] for p in pts]
         rows.append([Fraction(0)] * (cols - 1) + [Fraction(1)])
         return rows
-    Vn = vander(n)        # n x n
-    G = vander(3)         # n x 3
-    AT = [[Vn[i][j] if j < m else None for i in range(n)] for j in range(m)]   # placeholder, fixed below
-    # A^T = (evaluation matrix for degree m - 1)^T
+
     Am = vander(m)        # n x m
     AT = [[Am[i][j] for i in range(n)] for j in range(m)]
-    # B^T = inverse of Vn, transposed appropriately: B^T = (Vn^-1)^T ... computed by exact Gaussian elimination
-    inv = _inv(Vn)
-    BT = [[inv[j][i] for j in range(n)] for i in range(n)]
-    # scale rows of G / columns so that the identity holds: with Y = A^T[(G g)(.)(B^T d)], the exact identity needs the
-    # Lagrange normalisation folded into G: g' = G g / N_i where N_i = prod_{k != i}(p_i - p_k)
-    Gs = []
+    G3 = vander(3)        # n x 3
+    G = []
     for i in range(n - 1):
         Ni = Fraction(1)
         for k in range(n - 1):
             if k != i:
                 Ni *= (pts[i] - pts[k])
-        Gs.append([x / Ni for x in G[i]])
-    Gs.append(G[n - 1])
-    # and B^T rows become the numerator polynomials prod_{k != i}(x - p_k) (times (x - ...) for the infinity row)
+        G.append([x / Ni for x in G3[i]])
+    G.append(G3[n - 1])
     BT = []
     for i in range(n - 1):
         poly = [Fraction(1)]
@@ -67,7 +61,7 @@ def toom_cook(m, points):
         poly = _polymul(poly, [-pts[k], Fraction(1)])
     BT.append(poly)
     f = lambda M: np.array([[float(x) for x in r] for r in M], dtype=np.float64)
-    return f(AT), f(Gs), f(BT)
+    return f(AT), f(G), f(BT)
 
 
 def _polymul(a, b):
@@ -76,19 +70,6 @@ def _polymul(a, b):
         for j, y in enumerate(b):
             out[i + j] += x * y
     return out
-
-
-def _inv(M):
-    n = len(M)
-    A = [list(r) + [Fraction(int(i == j)) for j in range(n)] for i, r in enumerate(M)]
-    for c in range(n):
-        p = next(r for r in range(c, n) if A[r][c] != 0)
-        A[c], A[p] = A[p], A[c]
-        A[c] = [x / A[c][c] for x in A[c]]
-        for r in range(n):
-            if r != c and A[r][c] != 0:
-                A[r] = [x - A[r][c] * y for x, y in zip(A[r], A[c])]
-    return [r[n:] for r in A]
 
 
 def check_identity(AT, G, BT, m):
