@@ -127,6 +127,17 @@ int se3tn_get_winograd(const se3tn_ctx* ctx, int* min_batch, int* tile);
 #define SE3TN_TRUNK_WINOGRAD_DEFAULT_MIN_FILL 55   /* percent of the last round of workgroups; 0 = every launch with n >= min_batch */
 int se3tn_set_trunk_winograd(se3tn_ctx* ctx, int min_batch, int min_fill_percent);
 int se3tn_get_trunk_winograd(const se3tn_ctx* ctx, int* min_batch, int* min_fill_percent);
+/* Rounding of OffsetDepth's `depth -= pose[2,3]*1000` (data_augmentation.py:134-144: a float64 scalar subtracted from a float32 array):
+ *   SE3TN_OFFSET_RULE_NUMPY1 (default) what every NumPy the reference can run on does (it pins Python 3.6 => NumPy <= 1.19,
+ *                            docker/dockerfile:28; `np.float`, Utils.py:307, stops importing at 1.24): value-based casting, the
+ *                            scalar becomes float32 and the subtraction is ONE float32 operation;
+ *   SE3TN_OFFSET_RULE_NUMPY2 NEP 50 (NumPy >= 2, were the reference ported to it): float64 subtraction, rounded to float32 once.
+ * The two differ by <= 1 ulp(f32) on the offset depth and only when z * 1000 is not a float32 (tests/golden/preprocess_numpy1.npz
+ * was produced by the reference's own classes under NumPy 1.26.4, preprocess.npz under NumPy 2.2; the kernel matches each bit for bit). */
+#define SE3TN_OFFSET_RULE_NUMPY1 0
+#define SE3TN_OFFSET_RULE_NUMPY2 1
+int se3tn_set_offset_rule(se3tn_ctx* ctx, int rule);
+int se3tn_get_offset_rule(const se3tn_ctx* ctx);
 /* trans_normalizer / rot_normalizer of Tracker.__init__ (predict.py:128). */
 int se3tn_set_normalizers(se3tn_ctx* ctx, double trans_normalizer, double rot_normalizer);
 

@@ -15,6 +15,7 @@ NCHW, NHWC = 0, 1
 PREC_F32, PREC_F16X3 = 0, 1
 WINOGRAD_TILE_AUTO, WINOGRAD_TILE6_MIN_BATCH = 46, 14   # as include/se3tracknet.h: F(4x4) below 14 pairs, F(6x6) from there
 TRUNK_WINOGRAD_DEFAULT_MIN_BATCH, TRUNK_WINOGRAD_DEFAULT_MIN_FILL = 8, 55   # as include/se3tracknet.h (tests/test_host_abi.py)
+OFFSET_RULE_NUMPY1, OFFSET_RULE_NUMPY2 = 0, 1   # as include/se3tracknet.h: rounding of OffsetDepth's float64-scalar subtraction
 BLUR_NONE, BLUR_BILATERAL, BLUR_GAUSSIAN = 0, 1, 2
 RES = 176
 
@@ -55,6 +56,8 @@ _SIGS = {
     "se3tn_bind_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "se3tn_set_normalization": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "se3tn_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "se3tn_set_offset_rule": (C.c_int, [C.c_void_p, C.c_int]),
+    "se3tn_get_offset_rule": (C.c_int, [C.c_void_p]),
     "se3tn_set_winograd": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "se3tn_get_winograd": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "se3tn_set_trunk_winograd": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

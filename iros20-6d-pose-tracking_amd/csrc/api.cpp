@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,7 +34,7 @@ enum { MAX_LAUNCHES = 24, MAX_SLOTS = 64 };
 // one captured se3tn_infer: every argument that is baked into the kernel launches
 struct GraphKey {
   const void *A, *B, *trans, *rot, *poseA, *poseB, *blob;
-  int n, layout, prec, wino, wino64, wino64_fill;
+  int n, layout, prec, wino_min_batch, wino_tile, keep, wino64, wino64_fill;
   double tn, rn;
   bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
 };
@@ -89,6 +90,7 @@ struct se3tn_ctx {
   const float* wino_us_blob = nullptr;          // the blob / tile the split planes were derived for
   int wino_us_tile = 0;
   int prec = SE3TN_PREC_F32;                    // se3tn_set_precision
+  int offset_rule = SE3TN_OFFSET_RULE_NUMPY1;   // se3tn_set_offset_rule
   int in_split[2] = {0, 0};                     // pixel format currently held by inA / inB
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
   int* overflow = nullptr;                      // device flag: a split-row store left the f16 range
@@ -125,6 +127,20 @@ struct se3tn_mesh {
   int tw = 0, th = 0, tlevels = 0;
   unsigned tex_off[16] = {};
   float kd[3] = {1.f, 1.f, 1.f};
+};
+
+// Init-time entry points that allocate or launch (plane derivation, workspace growth) run on the CONTEXT's device whatever device the
+// calling thread has current (two contexts on two GPUs in one process: ADVICE r3), and leave the caller's current device as it was.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    if (device < 0) return;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) err = hipSetDevice(device);
+    else prev = -1;   // nothing to restore
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
 // ---- Winograd workspaces ----------------------------------------------------------------------------
@@ -168,6 +184,8 @@ static int wino64_prepare(se3tn_ctx* c, hipStream_t st) {
 }
 
 static int wino_prepare(se3tn_ctx* c, hipStream_t st) {
+  DeviceGuard dg(c->device);
+  HIPCHK(dg.err);
   if (int rc = wino64_prepare(c, st)) return rc;
   if (c->wino_min_batch <= 0 || c->max_batch < c->wino_min_batch) return SE3TN_OK;
   if (!c->wino_v) {
@@ -211,6 +229,8 @@ static int wino_prepare(se3tn_ctx* c, hipStream_t st) {
 // from se3tn_set_precision / se3tn_upload_weights / se3tn_bind_weights, never from a stream-ordered compute call)
 static int split_prepare(se3tn_ctx* c, hipStream_t st) {
   if (c->device < 0 || c->prec != SE3TN_PREC_F16X3 || !c->blob) return SE3TN_OK;
+  DeviceGuard dg(c->device);
+  HIPCHK(dg.err);
   if (c->split_blob != c->blob) {
     if (!c->split_w) HIPCHK(hipMalloc((void**)&c->split_w, c->SL.total * sizeof(float)));
     HIPCHK(launch_split_weights(c->blob, c->L, c->split_w, c->SL, st));
@@ -387,7 +407,8 @@ int se3tn_upload_weights(se3tn_ctx* c, void* stream) {
                         (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));  // init-time only: the host vector may go away
   c->blob = c->blob_owned;
-  c->wino_blob = nullptr;  // same address, new contents
+  c->wino_blob = nullptr;  // same address, new contents: every derived plane set follows the weights
+  c->wino6_blob = nullptr;
   c->wino64_blob = nullptr;
   c->split_blob = nullptr;
   c->wino_us_blob = nullptr;
@@ -398,12 +419,15 @@ int se3tn_upload_weights(se3tn_ctx* c, void* stream) {
 int se3tn_bind_weights(se3tn_ctx* c, const void* device_blob, size_t bytes) {
   if (!c || c->device < 0 || !device_blob) return fail(SE3TN_E_ARG, "se3tn_bind_weights: bad argument");
   if (bytes != c->L.total * sizeof(float)) return fail(SE3TN_E_SHAPE, "se3tn_bind_weights: blob size mismatch");
+  DeviceGuard dg(c->device);
+  HIPCHK(dg.err);
   uint32_t hdr[4];
   HIPCHK(hipMemcpy(hdr, device_blob, sizeof(hdr), hipMemcpyDeviceToHost));  // init-time validation
   if (hdr[0] != BLOB_MAGIC || hdr[1] != BLOB_VERSION || hdr[2] != (uint32_t)c->L.total)
     return fail(SE3TN_E_SHAPE, "se3tn_bind_weights: bad blob header");
   c->blob = (const float*)device_blob;
   c->wino_blob = nullptr;
+  c->wino6_blob = nullptr;
   c->wino64_blob = nullptr;
   c->split_blob = nullptr;
   c->wino_us_blob = nullptr;
@@ -506,6 +530,13 @@ int se3tn_overflow(se3tn_ctx* c, int* flag) {
   return SE3TN_OK;
 }
 
+int se3tn_set_offset_rule(se3tn_ctx* c, int rule) {
+  if (!c || (rule != SE3TN_OFFSET_RULE_NUMPY1 && rule != SE3TN_OFFSET_RULE_NUMPY2)) return fail(SE3TN_E_ARG, "se3tn_set_offset_rule: bad rule");
+  c->offset_rule = rule;
+  return SE3TN_OK;
+}
+int se3tn_get_offset_rule(const se3tn_ctx* c) { return c ? c->offset_rule : -1; }
+
 int se3tn_set_normalizers(se3tn_ctx* c, double tn, double rn) {
   if (!c) return fail(SE3TN_E_ARG, "null ctx");
   c->tn = tn;
@@ -537,6 +568,7 @@ int se3tn_preprocess(se3tn_ctx* c, const se3tn_crop* crops, int n, float* out, v
     // the context's input buffers hold split pixels in f16x3 mode (consumed by the f16 stem)
     a.split = (a.padded && c->prec == SE3TN_PREC_F16X3) ? 1 : 0;
     a.overflow = c->overflow;
+    a.offset_rule = c->offset_rule;
     if (a.padded) c->in_split[out == c->inA ? 0 : 1] = a.split;
     a.out = out + (size_t)i0 * (a.padded ? IN_P * IN_P : RES * RES) * 4;
     HIPCHK(launch_preprocess(a, (hipStream_t)stream));
@@ -561,6 +593,21 @@ static int prof_mark(se3tn_ctx* c, hipStream_t st, const char* name, bool is_con
   return (int)hipEventRecord(c->ev[c->n_launch], st);
 }
 
+// Profile names say which ALGORITHM a launch took ("convAB2.conv1 [F(6x6)]"): the tests assert from them that the path they mean to
+// check is the one that ran.  Interned once per (name, tile); the strings live as long as the library.
+static const char* algo_name(const char* name, int tile) {
+  static std::mutex mu;
+  static std::map<std::pair<std::string, int>, std::string> names;
+  std::lock_guard<std::mutex> lk(mu);
+  auto key = std::make_pair(std::string(name), tile);
+  auto it = names.find(key);
+  if (it == names.end()) {
+    const std::string t = std::to_string(tile);
+    it = names.emplace(key, std::string(name) + " [F(" + t + "x" + t + ")]").first;
+  }
+  return it->second.c_str();
+}
+
 static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int layout, float* trans, float* rot,
                         const double* poseA, double* poseB, void* stream);
 
@@ -581,7 +628,8 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
   std::memset(&key, 0, sizeof(key));
   key.A = A; key.B = B; key.trans = trans; key.rot = rot; key.poseA = poseA; key.poseB = poseB; key.blob = c->blob;
   key.n = n; key.layout = layout; key.prec = c->prec;
-  key.wino = ((c->wino_min_batch * 8 + c->wino_tile) * 2 + (c->keep_intermediates ? 1 : 0)); key.wino64 = c->wino64_min_batch; key.wino64_fill = c->wino64_min_fill; key.tn = c->tn; key.rn = c->rn;
+  key.wino_min_batch = c->wino_min_batch; key.wino_tile = c->wino_tile; key.keep = c->keep_intermediates ? 1 : 0;
+  key.wino64 = c->wino64_min_batch; key.wino64_fill = c->wino64_min_fill; key.tn = c->tn; key.rn = c->rn;
   hipStream_t st = (hipStream_t)stream;
   for (auto& g : c->graphs) {
     if (!(g.key == key)) continue;
@@ -687,7 +735,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
       w.u_gs = (long long)w.nf * s.cin * s.cout;
       hipError_t e = launch_wino_conv(w, epi, st);
       if (e != hipSuccess) return hipfail(e, name);
-      return prof_mark(c, st, name, true);
+      return prof_mark(c, st, c->prof ? algo_name(name, wtile) : name, true);
     }
     if (id <= L64_4 && !fast && wino64_pays(c, n, s.groups) && c->wino64_blob == c->blob && stride == 1 && hin == S2 && epi != 2) {
       const int slot64 = (int)id - (int)L64_1;
@@ -752,10 +800,10 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
       w.overflow = c->overflow;
       if (keep2) keep2 = c->head_f;   // the kept head activation is float32 (head itself holds split rows)
     }
-    MarkCtx mc{c, st, name1};
+    MarkCtx mc{c, st, c->prof ? algo_name(name1, 4) : name1};
     hipError_t e = launch_wino_block(w, U2, usc2, W + L.conv_b[id2], io, c->keep_intermediates ? 1 : 0, keep2, tl, st, mark_fn, &mc);
     if (e != hipSuccess) return hipfail(e, name2);
-    return prof_mark(c, st, name2, true);
+    return prof_mark(c, st, c->prof ? algo_name(name2, 4) : name2, true);
   };
   // f16x3 mode: the batched GEMMs of the 256-channel block are bandwidth-bound at the f16 matrix rate (41 FLOP per byte of V / M
   // traffic) and lose to the direct f16x3 kernels (0.247 vs 0.220 ms at batch 64); the 512-channel heads win (0.349 vs 0.427 ms)

@@ -209,8 +209,12 @@ __global__ __launch_bounds__(256) void fd_finish_kernel(const float* __restrict_
     // beyond max_depth stays NEGATIVE through dilate / close / fill / median (inverted depth max_depth - d < 0 is "empty"
     // and only its rim is filled), so e.g. -0.5 m -> -500 -> 65036, not 0.  Either value is "invalid" for OffsetDepth
     // (<= 100 or >= 2000 -> 2000, data_augmentation.py:136), but the uint16 frame is the reference's bit for bit.
+    // NumPy leaves an out-of-range float -> uint16 cast undefined; this is what NumPy 2.2 (the build that made the goldens) and the
+    // 1.x series do on x86-64 (cvttss2si, then the low 16 bits).  Values a 32-bit int cannot hold and NaN are made explicit here
+    // instead of relying on the device's own conversion: cvttss2si returns the "integer indefinite" 0x80000000 for them -> 0.
     const float mm = d * 1000.f;
-    out_mm[i] = (uint16_t)(unsigned)(int)mm;
+    const int iv = (mm >= -2147483648.f && mm < 2147483648.f) ? (int)mm : (int)0x80000000u;
+    out_mm[i] = (uint16_t)(unsigned)iv;
   }
 }
 

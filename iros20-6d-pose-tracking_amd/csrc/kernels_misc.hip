@@ -61,9 +61,10 @@ hipError_t launch_to_padded_input(const float* in, float* out, int n, int nchw, 
 // ------------------------------------------------------------------------------------------------
 // One thread per output pixel.  Index rule of cv2.resize(INTER_NEAREST) (OpenCV resizeNN):
 //   sx = min(floor(x * (1.0 / ((double)dst / src))), src - 1)      evaluated in float64,
-// the crop canvas is zero outside the frame (Utils.py:327-342).  float64 arithmetic mirrors
-// what NumPy does in the reference: depth offset in f64 then rounded to f32
-// (data_augmentation.py:137-140), (x - mean)/std in f64 then stored as f32 (:160-164, :182-187).
+// the crop canvas is zero outside the frame (Utils.py:327-342).  The arithmetic mirrors what NumPy does in the
+// reference: the depth offset (data_augmentation.py:137-140) as ONE float32 operation with the scalar cast to float32 first
+// (SE3TN_OFFSET_RULE_NUMPY1: value-based casting, every NumPy the reference runs on) or in float64 rounded once (NUMPY2, NEP 50);
+// (x - mean)/std in f64 then stored as f32 (:160-164, :182-187: array operands, float64 under both).
 __global__ __launch_bounds__(256) void preprocess_kernel(const CropArgs a) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= RES * RES) return;
@@ -85,7 +86,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const CropArgs a) {
   }
   const bool invalid = (d <= 100.f) || (d >= 2000.f);
   const double z = c.z_offset_mm;
-  d = (z < 0.0) ? (float)((double)d + z) : (float)((double)d - z);
+  if (a.offset_rule == SE3TN_OFFSET_RULE_NUMPY1) {
+    const float zf = (float)z;   // np.float64 scalar -> float32 (round to nearest even), then a float32 add / subtract
+    d = (z < 0.0) ? d + zf : d - zf;
+  } else {
+    d = (z < 0.0) ? (float)((double)d + z) : (float)((double)d - z);
+  }
   if (invalid) d = 2000.f;
   const double* mean = a.mean + 4 * c.stats;
   const double* sd = a.stdv + 4 * c.stats;

@@ -200,6 +200,7 @@ struct CropArgs {  // one launch handles up to MAX crops
   int n;
   int padded;
   int split;    // f16x3 mode: a pixel is stored as 4 x f16 hi | 4 x f16 lo (same 16 bytes)
+  int offset_rule;  // SE3TN_OFFSET_RULE_*: how `depth -= z` rounds (NumPy 1.x: one float32 operation; NumPy 2: float64, rounded once)
   int* overflow;
 };
 

@@ -133,6 +133,15 @@ class Engine:
         """_lib.PREC_F32 (default, exact) or _lib.PREC_F16X3 (split-f16 MFMA for the deep layers, n >= 32)."""
         check(self.lib.se3tn_set_precision(self._h, int(mode)), "se3tn_set_precision")
 
+    def set_offset_rule(self, rule):
+        """Rounding of OffsetDepth's `depth -= pose[2,3]*1000`: "numpy1" | _lib.OFFSET_RULE_NUMPY1 (default: one float32 operation, what
+        every NumPy the reference runs on does) or "numpy2" | _lib.OFFSET_RULE_NUMPY2 (float64, rounded once)."""
+        rule = {"numpy1": _lib.OFFSET_RULE_NUMPY1, "numpy2": _lib.OFFSET_RULE_NUMPY2}.get(rule, rule)
+        check(self.lib.se3tn_set_offset_rule(self._h, int(rule)), "se3tn_set_offset_rule")
+
+    def get_offset_rule(self):
+        return "numpy2" if self.lib.se3tn_get_offset_rule(self._h) == _lib.OFFSET_RULE_NUMPY2 else "numpy1"
+
     def set_winograd(self, min_batch, tile=0):
         """Batches of n >= min_batch run the 256/512-channel stride-1 convs as Winograd F(tile x tile,3x3)
         (float32; tile 2 | 4 | 6 | _lib.WINOGRAD_TILE_AUTO = 4 below 14 pairs, 6 from there; 0 = keep); min_batch 0 = always the direct

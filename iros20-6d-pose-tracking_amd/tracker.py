@@ -194,10 +194,11 @@ class Tracker:
         if n > self.engine.max_batch:
             raise ValueError("on_track_batch: %d pairs > max_samples=%d given to Tracker()" % (n, self.engine.max_batch))
         dev = self._dev
-        cropsA, cropsB, keep = [], [], []
+        cropsA, cropsB, keep, bboxes = [], [], [], []
         poses = np.stack([np.asarray(p, np.float64) for p in prev_poses])
         for i in range(n):
             bb = U.compute_bbox(poses[i], self.K, self.object_width, scale=(1000, 1000, 1000))
+            bboxes.append(bb)
             if isinstance(self.renderer, HipRenderer) and not self.renderer.full_frame:
                 rgbA_d = torch.empty((176, 176, 3), dtype=torch.uint8, device=dev)
                 depA_d = torch.empty((176, 176), dtype=torch.int16, device=dev)
@@ -219,5 +220,8 @@ class Tracker:
         self.engine.infer(self.engine.input_buffer_ptr(0), self.engine.input_buffer_ptr(1), n, NHWC,
                           self._trans, self._rot, self._poseA, self._poseB)
         out = self._poseB[:n].cpu().numpy().reshape(n, 4, 4)
+        # what on_track keeps in last_prediction / renderer.rgb, per pair (callers that log or check the step)
+        self.last_prediction = dict(trans=self._trans[:n].cpu().numpy(), rot=self._rot[:n].cpu().numpy(),
+                                    bbox=np.stack(bboxes), rgbA=keep[0::4], depthA=keep[1::4])
         self.frame_cnt += 1
         return out

@@ -185,33 +185,61 @@ def _obj_geometry_fast(lines):
     """Vectorised parse of the v / vt / f records of an .obj whose faces are all triangles written in ONE corner format
     (v, v/vt, v/vt/vn or v//vn) -- what scanners and Blender export.  Returns (pos [P,3], col [P,3], tex [T,2] | None,
     corner index pairs [F,3,2] (vi, ti; ti = -1 without texcoords)) or None when the file needs the general parser."""
-    vl = [l[2:] for l in lines if l.startswith("v ")]
-    tl = [l[3:] for l in lines if l.startswith("vt ")]
-    fl = [l[2:] for l in lines if l.startswith("f ")]
+    # records are selected as the general parser selects them (first whitespace-separated token), so tab-separated or indented
+    # records cannot be seen by one parser and missed by the other
+    vl, tl, fl = [], [], []
+    for l in lines:
+        t = l.split(None, 1)
+        if len(t) < 2:
+            if t and t[0] in ("v", "vt", "f"):
+                return None                           # a record without fields: let the general parser report it
+            continue
+        if t[0] == "v":
+            vl.append(t[1])
+        elif t[0] == "vt":
+            tl.append(t[1])
+        elif t[0] == "f":
+            fl.append(t[1])
     if not vl or not fl:
         return None
-    nv_tok = len(vl[0].split())
+
+    def uniform_tokens(recs):
+        """token count shared by EVERY record, or -1"""
+        cnt = np.fromiter((len(r.split()) for r in recs), dtype=np.int64, count=len(recs))
+        return int(cnt[0]) if (cnt == cnt[0]).all() else -1
+
+    nv_tok = uniform_tokens(vl)
     if nv_tok not in (3, 4, 6):
         return None
-    flat = np.array(" ".join(vl).split(), dtype=np.float64)
-    if flat.size != nv_tok * len(vl):
+    try:
+        flat = np.array(" ".join(vl).split(), dtype=np.float64)
+    except ValueError:
         return None
     vv = flat.reshape(len(vl), nv_tok)
     pos = vv[:, :3]
     col = vv[:, -3:] * 255.0 if nv_tok >= 6 else np.full((len(vl), 3), 255.0)
     tex = None
     if tl:
-        nt_tok = len(tl[0].split())
-        tflat = np.array(" ".join(tl).split(), dtype=np.float64)
-        if nt_tok < 1 or tflat.size != nt_tok * len(tl):
+        nt_tok = uniform_tokens(tl)
+        if nt_tok < 1:
+            return None
+        try:
+            tflat = np.array(" ".join(tl).split(), dtype=np.float64)
+        except ValueError:
             return None
         tt = tflat.reshape(len(tl), nt_tok)
         tex = np.stack([tt[:, 0], tt[:, 1] if nt_tok > 1 else np.zeros(len(tl))], 1)
-    first = fl[0].split()
-    if len(first) != 3:
+    # every face a triangle, every corner in the SAME format: per-line token and '/' counts (a file that mixes "1/1 2/2 3/3" with
+    # "1 2 3 4 5 6" has matching flattened counts and must not be accepted: ADVICE r3)
+    if uniform_tokens(fl) != 3:
         return None
+    first = fl[0].split()
     nslash = first[0].count("/")
     double = "//" in first[0]
+    nsl = np.fromiter((r.count("/") for r in fl), dtype=np.int64, count=len(fl))
+    ndb = np.fromiter((r.count("//") for r in fl), dtype=np.int64, count=len(fl))
+    if not (nsl == 3 * nslash).all() or not (ndb == (3 if double else 0)).all():
+        return None
     joined = " ".join(fl)
     if double:
         joined = joined.replace("//", "/0/")
@@ -221,7 +249,7 @@ def _obj_geometry_fast(lines):
     except ValueError:
         return None
     if ints.size != len(fl) * 3 * ncomp:
-        return None                                   # polygons or mixed corner formats
+        return None                                   # an empty slot ("1/ 2/ 3/"): general parser
     c = ints.reshape(len(fl), 3, ncomp)
     if (c[..., 0] <= 0).any() or (ncomp >= 2 and not double and (c[..., 1] < 0).any()):
         return None                                   # relative (negative) indices depend on the line order

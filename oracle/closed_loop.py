@@ -65,7 +65,7 @@ def _frames():
     return [Fx.structured_frame(400 + i) for i in range(N_DISTINCT_FRAMES)]
 
 
-def make_tracker(se3, subdiv=5, precision=None, regime="ycb_video_5deg", seq=None):
+def make_tracker(se3, subdiv=5, precision=None, regime="ycb_video_5deg", seq=None, max_samples=8):
     """Tracker with random-init weights whose FC biases are centred on a calibration set (so that the outputs are not a
     saturated constant).  The calibration runs the ORACLE on N_CALIB (pose, frame) pairs with the image A the HIP
     rasteriser renders for those poses; it only chooses the weights both sides then use."""
@@ -75,7 +75,7 @@ def make_tracker(se3, subdiv=5, precision=None, regime="ycb_video_5deg", seq=Non
     sd = O.make_state_dict(0, head_gain=HEAD_GAIN)
     mesh = R.icosphere(subdiv, 0.06, 0)                   # 20 * 4^subdiv faces
     trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=OBJECT_WIDTH_MM), mean, std, {"state_dict": sd},
-                      trans_normalizer=tn, rot_normalizer=rn)
+                      trans_normalizer=tn, rot_normalizer=rn, max_samples=max_samples)
     trk.renderer = se3.HipRenderer(trk.engine, mesh)
     seq = seq or _frames()
     logits = []
@@ -169,6 +169,82 @@ def run_regime(se3, regime, frames=300, check=True, subdiv=5, precision=None, ti
                    ok=bool(bbox_mismatch == 0 and e_net <= 1e-4 and e_logit <= 1e-4 and e_pose <= 1e-5))
         if poses_timed is not None:
             out["timed_vs_checked_pass_max_abs_pose"] = replay_diff   # the two passes are the same deterministic track
+    return out
+
+
+def run_regime_batch(se3, regime, tracks, frames=50, subdiv=4, winograd=None):
+    """`tracks` INDEPENDENT closed-loop tracks advanced together through ``Tracker.on_track_batch`` (one engine call of n = tracks
+    pairs per frame): the configuration where the large-batch algorithms of the library -- Winograd F(6x6) blocks from 14 pairs,
+    the fused trunk kernel in whole rounds of workgroups -- meet the binding tolerance (30-degree normaliser: a logit error is
+    amplified 6 x into the pose, 1e-5).  Track k starts from its own pose, follows the anchor trajectory with its own phase and
+    reads the frame sequence with its own offset; every pair of every frame is checked against the oracle (network forward
+    batched over the tracks, everything else per pair) fed the image A the HIP rasteriser rendered for that pair.
+    Returns the per-regime block of run_regime plus `launches`: the 256/512-channel conv launches of one profiled frame."""
+    import torch
+    seq = _frames()
+    trk, sd, (mean, std), nfaces = make_tracker(se3, subdiv, None, regime, seq, max_samples=tracks)
+    if winograd is not None:
+        trk.engine.set_winograd(*winograd)
+    tn, rn = REGIMES[regime]
+    n = tracks
+    phase = [37 * k for k in range(n)]
+    foff = [5 * k for k in range(n)]
+    P = []
+    for k in range(n):
+        Pk = Fx.pose(3 + k, (0.0, 0.0, 0.8))
+        Pk[:3, 3] = anchor(phase[k])
+        P.append(Pk)
+    bbox_mismatch = reinits = 0
+    e_net = e_pose = e_logit = 0.0
+    outs, bboxes = [], []
+    launches = None
+    for f in range(frames):
+        rgbs = [seq[(f + foff[k]) % N_DISTINCT_FRAMES][0] for k in range(n)]
+        deps = [seq[(f + foff[k]) % N_DISTINCT_FRAMES][1] for k in range(n)]
+        if f == 1:
+            trk.engine.profile_enable(1)
+        Q = trk.on_track_batch(P, rgbs, deps)
+        if f == 1:
+            torch.cuda.synchronize()
+            launches = [nm for nm, _ in trk.engine.profile_launches(0) if nm.startswith("conv")]
+            trk.engine.profile_enable(0)
+        lg = trk.engine.logits(n).cpu().numpy()
+        lp = trk.last_prediction
+        A, B, bbs = [], [], []
+        for k in range(n):
+            rgbA = lp["rgbA"][k].cpu().numpy()
+            depthA = lp["depthA"][k].cpu().numpy().view(np.uint16)
+            bb = O.compute_bbox(P[k], trk.K, trk.object_width, scale=(1000, 1000, 1000))
+            rgbB, depthB = O.crop_bbox(rgbs[k], deps[k], bb, (rgbA.shape[1], rgbA.shape[0]))
+            a, b = O.process_data(rgbA, depthA, P[k], rgbB, depthB, mean, std)
+            A.append(a); B.append(b); bbs.append(bb)
+        ref = O.forward(sd, torch.from_numpy(np.stack(A)), torch.from_numpy(np.stack(B)))
+        rt, rr = ref["trans"].numpy(), ref["rot"].numpy()
+        rl = np.concatenate([ref["trans_logit"].numpy(), ref["rot_logit"].numpy()], 1)
+        for k in range(n):
+            want = O.process_predict(P[k], rt[k], rr[k], tn, rn)
+            bbox_mismatch += int(not np.array_equal(lp["bbox"][k], bbs[k]))
+            e_pose = max(e_pose, float(np.abs(Q[k] - want).max()))
+            bboxes.append(bbs[k].reshape(-1))
+        e_net = max(e_net, float(np.abs(np.c_[lp["trans"], lp["rot"]] - np.c_[rt, rr]).max()))
+        e_logit = max(e_logit, float(np.abs(lg - rl).max()))
+        outs.append(np.c_[rt, rr])
+        for k in range(n):
+            N = Q[k].copy()
+            N[:3, 3] = anchor(f + 1 + phase[k]) + (Q[k][:3, 3] - P[k][:3, 3])
+            if _lost(N):
+                N[:3, 3] = anchor(f + 1 + phase[k])
+                reinits += 1
+            P[k] = N
+    signed = np.concatenate(outs, 0)
+    out = {"trans_normalizer": tn, "rot_normalizer_deg": round(rn * 180 / np.pi, 3), "frames": frames, "tracks": n, "faces": nfaces,
+           "pairs_checked": frames * n, "bbox_mismatches": bbox_mismatch,
+           "distinct_bboxes": int(len(np.unique(np.array(bboxes), axis=0))),
+           "max_abs_logit_diff": e_logit, "max_abs_trans_rot": e_net, "max_abs_pose": e_pose,
+           "median_abs_trans_rot": round(float(np.median(np.abs(signed))), 4),
+           "std_trans_rot": [round(float(v), 4) for v in signed.std(0)],
+           "max_abs_output": round(float(np.abs(signed).max()), 4), "reinits": reinits, "launches": launches,
+           "ok": bool(bbox_mismatch == 0 and e_net <= 1e-4 and e_logit <= 1e-4 and e_pose <= 1e-5)}
     return out
 
 

@@ -87,6 +87,10 @@ LARGE_CASES = [
     ("network_big_n8", 7, 0.002, 12, 8, 40.0),
     ("network_huge_n8", 9, 0.0005, 13, 8, 150.0),
     ("network_n64", 0, 0.05, 5, 64, 1.0),
+    # n = 16 >= SE3TN_WINOGRAD_TILE6_MIN_BATCH (14): SE3TN_WINOGRAD_TILE_AUTO runs F(6x6,3x3) here -- the engine's default algorithm for
+    # BASELINE's batch -- on the same large-magnitude inputs
+    ("network_big_n16", 7, 0.002, 14, 16, 40.0),
+    ("network_huge_n16", 9, 0.0005, 15, 16, 150.0),
 ]
 
 

@@ -210,15 +210,33 @@ def crop_bbox(color, depth, boundingbox, output_size=(176, 176)):
     return rgb * (rgb != 0), dep * (dep != 0)
 
 
-def normalize_depth(depth, pose):
-    """OffsetDepth.normalize_depth  data_augmentation.py:134-144."""
+OFFSET_RULE = "numpy1"   # the default of the library too (include/se3tracknet.h: SE3TN_OFFSET_RULE_NUMPY1)
+
+
+def normalize_depth(depth, pose, offset_rule=None):
+    """OffsetDepth.normalize_depth  data_augmentation.py:134-144.  `depth -= pose[2,3]*1000` subtracts a float64 SCALAR from a
+    float32 array, and what that means depends on the NumPy generation:
+      "numpy1"  value-based casting (every NumPy the reference can run on: it pins Python 3.6 => NumPy <= 1.19, docker/dockerfile:28,
+                and Utils.py:307 `np.float` stops importing at 1.24): the scalar is cast to float32, the subtraction is a float32
+                operation.  Pinned by tests/golden/preprocess_numpy1.npz (the reference's own class under NumPy 1.26.4,
+                oracle/make_numpy1_golden.py);
+      "numpy2"  NEP 50: float64 arithmetic, rounded to float32 once.  Pinned by tests/golden/preprocess.npz (made in this image's
+                main interpreter).  <= 1 ulp(f32) from "numpy1"."""
+    rule = offset_rule or OFFSET_RULE
     depth = depth.astype(np.float32)
     invalid = np.logical_or(depth <= 100, depth >= 2000)
     z_mm = np.float64(pose[2, 3]) * 1000
-    if pose[2, 3] < 0:
-        depth = (depth.astype(np.float64) + z_mm).astype(np.float32)
+    if rule == "numpy1":
+        z32 = np.float32(z_mm)
+        depth = (depth + z32) if pose[2, 3] < 0 else (depth - z32)
+        assert depth.dtype == np.float32
+    elif rule == "numpy2":
+        if pose[2, 3] < 0:
+            depth = (depth.astype(np.float64) + z_mm).astype(np.float32)
+        else:
+            depth = (depth.astype(np.float64) - z_mm).astype(np.float32)
     else:
-        depth = (depth.astype(np.float64) - z_mm).astype(np.float32)
+        raise ValueError(rule)
     depth[invalid] = 2000
     return depth
 
@@ -236,13 +254,13 @@ def normalize_channels(rgb_hwc_f32, depth_f32, mean, std):
     return buf
 
 
-def process_data(rgbA, depthA, A_in_cam, rgbB, depthB, mean, std):
+def process_data(rgbA, depthA, A_in_cam, rgbB, depthB, mean, std, offset_rule=None):
     """TrackDataset.processData with the eval posttransforms
     OffsetDepth -> NormalizeChannels -> ToTensor (datasets.py:115-136, predict.py:189).
     Both depths are offset by poseA (data_augmentation.py:130-131).
     Returns (dataA, dataB) float32 [4,H,W]."""
-    dA = normalize_depth(depthA, A_in_cam)
-    dB = normalize_depth(depthB, A_in_cam)
+    dA = normalize_depth(depthA, A_in_cam, offset_rule)
+    dB = normalize_depth(depthB, A_in_cam, offset_rule)
     a = normalize_channels(rgbA.astype(np.float32), dA, mean[:4], std[:4])
     b = normalize_channels(rgbB.astype(np.float32), dB, mean[4:], std[4:])
     return a, b
@@ -283,12 +301,12 @@ def process_predict(A_in_cam, trans_pred, rot_pred, trans_normalizer=0.03,
 
 
 def on_track(sd, prev_pose, rgb, depth, rgbA, depthA, K, object_width, mean, std,
-             trans_normalizer=0.03, rot_normalizer=5 * np.pi / 180):
+             trans_normalizer=0.03, rot_normalizer=5 * np.pi / 180, offset_rule=None):
     """Composition of the inner functions of Tracker.on_track (predict.py:217-296) with the
     rendered (rgbA, depthA) supplied by the caller (the renderer is out of scope)."""
     bb = compute_bbox(prev_pose, K, object_width, scale=(1000, 1000, 1000))
     rgbB, depthB = crop_bbox(rgb, depth, bb, (rgbA.shape[1], rgbA.shape[0]))
-    a, b = process_data(rgbA, depthA, prev_pose, rgbB, depthB, mean, std)
+    a, b = process_data(rgbA, depthA, prev_pose, rgbB, depthB, mean, std, offset_rule)
     out = forward(sd, torch.from_numpy(a)[None], torch.from_numpy(b)[None])
     pose = process_predict(prev_pose, out["trans"][0].numpy(), out["rot"][0].numpy(),
                            trans_normalizer, rot_normalizer)

@@ -359,9 +359,8 @@ class _PlyData:
 
     @staticmethod
     def read(path):
-        import importlib
-        U = importlib.import_module("iros20-6d-pose-tracking_amd.utils")
-        raw = U._read_ply(path)
+        from . import ply_io
+        raw = ply_io.read_ply(path)
         out = {"vertex": {k: np.asarray(v) for k, v in raw["vertex"].items()}}
         f = raw["face"]["vertex_indices"]
         out["face"] = {"vertex_indices": [np.asarray(r) for r in np.asarray(f)]}

@@ -75,3 +75,37 @@ def test_missing_gpus_is_reported_unmeasured_not_extrapolated():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3"], capture_output=True, text=True, env=_env(),
                        cwd=ROOT, timeout=300)
     assert r.returncode != 0 and "UNMEASURED" in r.stderr and r.stdout.strip() == ""
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("every_step", [False, True], ids=["gather-once", "gather-every-step"])
+def test_rccl_path_of_bench_at_world_size_one(every_step):
+    """RCCL itself entered on the GPU box.  The driver's launch line with ONE rank and SE3TN_FORCE_DIST=1:
+    `nccl` backend (= RCCL), a real ncclBroadcast of the 54 MB packed blob into se3tn_bind_weights
+    (dist.load_weights_everywhere), a real all_gather_into_tensor of the poses (once per timed region, and the asynchronous
+    per-step variant), the parity block checked on the very batch that was computed from the broadcast weights, stdout exactly
+    one JSON line.  A 1-GPU box cannot give a scaling curve and none is derived from this."""
+    env = _env()
+    env["SE3TN_FORCE_DIST"] = "1"
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+           "--track-frames", "0"]
+    if every_step:
+        cmd.append("--gather-every-step")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=840)
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = _one_json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["backend"] == "nccl", {k: out.get(k) for k in ("n_gpus", "rccl_ranks", "backend")}
+    assert out["parity"]["ok"], out["parity"]
+    assert out["value"] > 0 and len(out["per_rank_pairs_per_s"]) == 1
+    assert "dry_run" not in out
+    if every_step:
+        assert "every step" in out["config"]["parallelism"]

@@ -59,6 +59,27 @@ def test_closed_loop_300_frames_per_frame_parity(se3, regime):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tracks", [16, 64])
+def test_closed_loop_batched_tracks_30deg_run_the_large_batch_algorithms(se3, tracks):
+    """`tracks` independent closed-loop tracks per engine call (Tracker.on_track_batch) under the 30-degree
+    normaliser of predict.py:586 -- the library's large-batch default (Winograd F(6x6,3x3) for the 256/512-channel blocks from 14
+    pairs, the fused F(2x2) trunk kernel where its workgroups fill whole rounds) where the 1e-5 pose tolerance binds.  60 frames,
+    every pair of every frame against the oracle; the launch names of a profiled frame must name the algorithms."""
+    frames = 60
+    r = closed_loop.run_regime_batch(se3, "ycbineoat_30deg", tracks, frames=frames)
+    print(tracks, {k: v for k, v in r.items() if k != "launches"}, r["launches"])
+    blocks = [nm for nm in r["launches"] if nm.startswith("convAB2") or nm.startswith("trans|rot conv2")]
+    assert len(blocks) == 4 and all("[F(6x6)]" in nm for nm in blocks), r["launches"]
+    if tracks == 64:
+        assert sum("fused F(2x2)" in nm for nm in r["launches"]) == 4, r["launches"]
+    assert r["pairs_checked"] == frames * tracks and r["bbox_mismatches"] == 0, r
+    assert r["max_abs_logit_diff"] <= 1e-4 and r["max_abs_trans_rot"] <= 1e-4 and r["max_abs_pose"] <= 1e-5, r
+    assert r["median_abs_trans_rot"] >= 0.05 and min(r["std_trans_rot"]) >= 0.02 and r["max_abs_output"] < 0.999, r
+    assert r["distinct_bboxes"] >= frames * tracks // 4 and r["reinits"] == 0, r
+    assert r["ok"]
+
+
+@pytest.mark.gpu
 def test_closed_loop_f16x3_mode(se3):
     r = closed_loop.run_regime(se3, "ycbineoat_30deg", frames=60, check=True, timing=False, precision=se3._lib.PREC_F16X3)
     assert r["bbox_mismatches"] == 0 and r["max_abs_trans_rot"] <= 1e-4 and r["max_abs_pose"] <= 1e-5, r

@@ -34,7 +34,7 @@ def test_reference_driver_golden_facts(golden, tmp_path):
         rgb = np.array(Image.open(os.path.join(video, "rgb", "%07d.png" % i)))[:, :, :3]
         depth = np.array(Image.open(os.path.join(video, "depth_filled", "%07d.png" % i))).astype(np.uint16)
         want, _ = O.on_track(sd, golden["poses_in"][i], rgb, depth, golden["rgbA"][i], golden["depthA"][i], Fx.K_YCB, OBJECT_WIDTH,
-                             mean, std, 0.03, 30 * np.pi / 180)
+                             mean, std, 0.03, 30 * np.pi / 180, offset_rule="numpy2")   # the golden: the reference under NumPy 2
         assert np.abs(want - golden["poses"][i]).max() < 1e-6, i
 
 

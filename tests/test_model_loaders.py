@@ -148,6 +148,24 @@ def test_obj_fast_parser_equals_general_parser(U, tmp_path):
     for txt in ("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n", "v 0 0 0\nv 1 0 0\nv 1 1 0\nf -3 -2 -1\n",
                 "v 0 0 0\nv 1 0 0\nv 1 1 0\nf 1/ 2/ 3/\n"):
         assert U._obj_geometry_fast(txt.splitlines()) is None
+    # mixed corner formats / separators whose FLATTENED token counts happen to match one format: the fast parser either
+    # declines or agrees with the general parser -- never a silently different mesh
+    tri = "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 2 2 0\nv 3 3 0\nvt 0 0\nvt 1 0\nvt 1 1\n"
+    for body in ("f 1/1 2/2 3/3\nf 1 2 3 4 5 6\n",             # 2 x 6 ints either way
+                 "f 1/1/1 2/2/2 3/3/3\nf 1//1 2//2 3//3\n",     # same '/' count per line, different meaning
+                 "f 1/1 2/2 3/3\nf 1 2 3\nf 4 5 6\n",
+                 "f\t1/1\t2/2\t3/3\n  f 2/2 3/3 4/1\n",          # tab-separated and indented records
+                 "f 1 2 3\n\tv 9 9 9\nf 2 3 7\n"):              # an indented vertex record between the faces
+        lines = (tri + body).splitlines()
+        fast = U._obj_geometry_fast(lines)
+        if fast is None:
+            continue
+        (tmp_path / "mix.obj").write_text(tri + body)
+        got, want = U.load_obj_mesh(str(tmp_path / "mix.obj")), U._load_obj_geometry_general(lines)
+        for k in ("vertices", "faces", "colors"):
+            assert np.array_equal(got[k], want[k]), (body, k)
+    assert U._obj_geometry_fast((tri + "f 1/1 2/2 3/3\nf 1 2 3 4 5 6\n").splitlines()) is None
+    assert U._obj_geometry_fast((tri + "f 1/1/1 2/2/2 3/3/3\nf 1//1 2//2 3//3\n").splitlines()) is None
     (tmp_path / "vc.obj").write_text("v 0 0 0 1 0 0\nv 1 0 0 0 1 0\nv 1 1 0 0 0 1\nf 1 2 3\n")
     m = U.load_obj_mesh(str(tmp_path / "vc.obj"))
     assert m["colors"].tolist() == [[255.0, 0, 0], [0, 255.0, 0], [0, 0, 255.0]]

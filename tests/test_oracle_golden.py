@@ -108,7 +108,7 @@ def test_on_track_composition(golden_dir):
     for f in range(3):
         rgb, depth = Fx.synthetic_frame(30 + f)
         rgbA, depthA = Fx.synthetic_render(130 + f, P[2, 3])
-        P, info = O.on_track(sd, P, rgb, depth, rgbA, depthA, Fx.K_YCB, 250.0, mean, std)
+        P, info = O.on_track(sd, P, rgb, depth, rgbA, depthA, Fx.K_YCB, 250.0, mean, std, offset_rule="numpy2")   # golden made under NumPy 2
         assert (info["bbox"] == g["bbox"][f]).all()
         np.testing.assert_allclose(info["trans"], g["trans"][f], rtol=0, atol=1e-5)
         np.testing.assert_allclose(info["rot"], g["rot"][f], rtol=0, atol=1e-5)
@@ -122,3 +122,39 @@ def test_resize_nearest_rule():
     assert idx[0] == 0 and idx[-1] == int(np.floor(175 * (1.0 / (176 / 333)))) and idx.max() <= 332
     up = O.resize_nearest_indices(176, 67)
     assert up[0] == 0 and up[-1] == 66 and (np.diff(up) >= 0).all()
+
+
+def test_offset_depth_under_the_numpy_the_reference_pins(golden_dir):
+    """tests/golden/preprocess_numpy1.npz: the reference's OffsetDepth / NormalizeChannels / ToTensor run UNMODIFIED under NumPy
+    1.26.4 (value-based casting, like the NumPy <= 1.19 the reference pins; oracle/make_numpy1_golden.py).  The oracle's "numpy1"
+    rule reproduces it bit for bit on every case, its "numpy2" rule reproduces what the same classes give under NumPy 2; the two
+    differ (by <= 1 ulp of float32 before normalisation) exactly on the poses whose z * 1000 is not a float32."""
+    from oracle.make_numpy1_golden import OFFSET_CASES
+    g = _load(golden_dir, "preprocess_numpy1.npz")
+    assert str(g["numpy_version"]).startswith("1.")
+    mean, std = Fx.mean_std(0)
+    cases = [(n, s, (t, w)) for n, s, t, w in PRE_CASES] + [(n, s, z) for n, s, z in OFFSET_CASES]
+    ndiff_total = 0
+    for name, seed, extra in cases:
+        if isinstance(extra, tuple):
+            t, width = extra
+            rgb, depth = Fx.synthetic_frame(seed)
+            P = Fx.pose(seed, t)
+            rgbA, depthA = Fx.synthetic_render(seed + 100, t[2])
+            rgbB, depthB = O.crop_bbox(rgb, depth, O.compute_bbox(P, Fx.K_YCB, width, scale=(1000, 1000, 1000)), (176, 176))
+        else:
+            P = Fx.pose(seed, (0.02, -0.01, extra))
+            rgbA, depthA = Fx.synthetic_render(seed + 100, abs(extra))
+            rgbB, depthB = Fx.synthetic_render(seed + 200, abs(extra))
+        assert np.array_equal(P, g[name + "_pose"])
+        a1, b1 = O.process_data(rgbA, depthA, P, rgbB, depthB, mean, std, offset_rule="numpy1")
+        a2, b2 = O.process_data(rgbA, depthA, P, rgbB, depthB, mean, std, offset_rule="numpy2")
+        assert Fx.sha(a1) == str(g[name + "_dataA_sha"]) and Fx.sha(b1) == str(g[name + "_dataB_sha"]), name
+        assert Fx.sha(a2) == str(g[name + "_dataA_sha_numpy2"]) and Fx.sha(b2) == str(g[name + "_dataB_sha_numpy2"]), name
+        nd = int((a1 != a2).sum() + (b1 != b2).sum())
+        assert nd == int(g[name + "_dataA_ndiff_vs_numpy2"]) + int(g[name + "_dataB_ndiff_vs_numpy2"])
+        assert (nd > 0) == (np.float64(np.float32(P[2, 3] * 1000)) != P[2, 3] * 1000), name
+        assert np.abs(a1.astype(np.float64) - a2).max() <= 4e-6 and np.array_equal(a1[:3], a2[:3])   # depth channel only, <= 1 ulp
+        ndiff_total += nd
+    assert ndiff_total > 10000     # the fractional-z cases really separate the two rules
+    assert O.OFFSET_RULE == "numpy1"
