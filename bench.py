@@ -384,15 +384,28 @@ def main():
     # MFMA flops the conv family actually executes: the Winograd layers do (tile+2)^2 multiplies per
     # tile x tile outputs (incl. the rows / columns computed past the map edge) instead of 9 per output
     wino_min, wino_tile_sel = eng.get_winograd()
-    # SE3TN_WINOGRAD_TILE_AUTO (the default): F(4x4) fused blocks below SE3TN_WINOGRAD_TILE6_MIN_BATCH pairs, F(6x6) from there
-    wino_tile = wino_tile_sel if wino_tile_sel != se3._lib.WINOGRAD_TILE_AUTO else (6 if nb >= se3._lib.WINOGRAD_TILE6_MIN_BATCH else 4)
-    wino_on = args.precision == "f32" and wino_min > 0 and nb >= wino_min
+    layers = eng.profile_launches(slots - 1)
+
+    def tile_of(name):
+        """Winograd tile of a conv launch, from the algorithm tag the library puts into its profile names ("[F(6x6)]"); 0 = direct."""
+        import re
+        m_ = re.search(r"\[F\((\d)x\1\)\]", name)
+        return int(m_.group(1)) if m_ else 0
+    WINO_LAYERS = {"convAB2.conv1": (22, 256, 256, 1), "convAB2.conv2": (22, 256, 256, 1),      # name prefix -> (hw, cin, cout, groups)
+                   "trans|rot conv2.conv1": (11, 512, 512, 2), "trans|rot conv2.conv2": (11, 512, 512, 2)}
     executed_per_pair = CONV3_FLOP_PER_PAIR
-    if wino_on:
-        nf = (wino_tile + 2) ** 2
-        for hw, cin, cout, convs in ((22, 256, 256, 2), (11, 512, 512, 4)):   # AB2.conv1/2; trans|rot conv2.conv1/2
-            tiles = (-(-hw // wino_tile)) ** 2
-            executed_per_pair += convs * 2 * cin * cout * (nf * tiles - 9 * hw * hw)
+    wino_tiles = {}
+    for name, _ in layers:
+        key = next((k for k in WINO_LAYERS if name.startswith(k)), None)
+        t_ = tile_of(name)
+        if key is None or not t_:
+            continue
+        hw, cin, cout, groups = WINO_LAYERS[key]
+        wino_tiles[key] = t_
+        executed_per_pair += groups * 2 * cin * cout * ((t_ + 2) ** 2 * (-(-hw // t_)) ** 2 - 9 * hw * hw)
+    wino_on = bool(wino_tiles)
+    wino_tile = max(wino_tiles.values()) if wino_tiles else 0     # (descriptions only: the per-launch tiles are in roofline.launches)
+    wino_desc = "/".join("F(%dx%d)" % (t_, t_) for t_ in sorted(set(wino_tiles.values()), reverse=True))
     layers = eng.profile_launches(slots - 1)
     # the 64-channel trunk launches that took the fused Winograd F(2x2) kernel (the library decides per launch: whole rounds of
     # workgroups only; the launch name says so): 4 quadrants x 32 steps x (128 x 64 x 32) MACs per image and group instead of
@@ -420,8 +433,8 @@ def main():
         ms = float(np.mean([d_[name] for d_ in per_slot if name in d_]))
         if name in trunk_fused:
             fl = float(TRUNK_FUSED_FLOP) * groups * nb
-        elif wcap and wino_on:
-            fl = 2.0 * cin * cout * groups * (wino_tile + 2) ** 2 * (-(-hw // wino_tile)) ** 2 * nb
+        elif wcap and tile_of(name):
+            fl = 2.0 * cin * cout * groups * (tile_of(name) + 2) ** 2 * (-(-hw // tile_of(name))) ** 2 * nb
         else:
             fl = 2.0 * cin * cout * groups * 9 * hw * hw * nb
         per_layer.append({"launch": name, "ms": round(ms, 4), "gflop_executed": round(fl / 1e9, 2),
@@ -535,8 +548,8 @@ def main():
             c4 = float(np.mean([eng.profile_read(s_)[0] for s_ in range(sl)]))
             eng.profile_enable(0)
             ex4 = executed_per_pair - sum((2 if "|" in n_ else 1) * (TRUNK_FUSED_FLOP - TRUNK_DIRECT_FLOP) for n_ in trunk_fused)
-            direct["trunk_direct"] = {"algorithm": "Winograd F(%dx%d) blocks as in the headline, 64-channel trunk on the direct kernels "
-                                                   "(se3tn_set_trunk_winograd(ctx, 0))" % (wino_tile, wino_tile),
+            direct["trunk_direct"] = {"algorithm": "Winograd %s blocks as in the headline, 64-channel trunk on the direct kernels "
+                                                   "(se3tn_set_trunk_winograd(ctx, 0))" % wino_desc,
                                       "value": round(world * nb * steps_timed / dt4, 1), "unit": "pairs/s",
                                       "ms_per_step": round(dt4 / steps_timed * 1e3, 4), "conv_ms_per_step": round(c4, 4),
                                       "flop_per_step_executed": ex4 * nb,
@@ -578,8 +591,8 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": "3x3 conv family, 10 convs/step on exact-f32 v_mfma_f32_32x32x2_f32: direct implicit GEMM "
                                    "(conv3x3_slab_kernel, conv3x3_gather_s2_kernel)" +
-                                   (" + Winograd F(%dx%d,3x3) for AB2.* and trans|rot conv2.* (wino_input/gemm/output_kernel)"
-                                    % (wino_tile, wino_tile) if wino_on else "") +
+                                   (" + Winograd %s (3x3) fused residual blocks for AB2.* and trans|rot conv2.* (wino_input / gemm / mid / "
+                                    "output | tail kernels)" % wino_desc if wino_on else "") +
                                    (" + fused Winograd F(2x2,3x3) for the 64-channel trunk (wino64_fused_kernel: %d of its 4 launches)"
                                     % len(trunk_fused) if trunk_fused else ""),
                          # achieved / frac = the MFMA flops the family EXECUTES (Winograd layers: (tile+2)^2 multiplies per
@@ -624,8 +637,13 @@ def main():
             out["alt_precision"] = other
         if direct is not None:
             out["alt_algorithm"] = direct
-        prof = pmc_traffic(nb, wino_on, bool(trunk_fused), wino_tile)
+        prof = pmc_traffic(nb)
         if prof is not None:
+            # PMC counters need rocprofv3 around the process, so the line quotes the newest COMMITTED profile of this command (per step
+            # of the conv family, FETCH_SIZE x 2 + WRITE_SIZE) and says so; `traffic_from_profile` has the details
+            out["roofline"]["traffic"] = prof["bytes_per_step"]
+            out["roofline"]["traffic_unit"] = "bytes per step (conv family), HBM + Infinity Cache"
+            out["roofline"]["traffic_source"] = prof["source"] + " (committed rocprofv3 PMC passes of this command; not measured by this run)"
             out["roofline"]["traffic_from_profile"] = prof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(O, sd, nb, oracle_inputs)
@@ -758,76 +776,37 @@ def check_timed_batch(np, torch, se3, O, eng, sd, nb, frames_rgb, frames_d, rend
     return res, (A, B)
 
 
-def pmc_traffic(nb, wino_on, trunk_fused=False, wino_tile=4):
-    """HBM bytes per step of the conv3x3 family from the newest COMMITTED rocprofv3 PMC summary
-    (profiles/*_pmc.json: FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, KB, separate passes of this same
-    command at batch 64).  NOT measured by this run (PMC needs rocprofv3 around the process): reported as
-    traffic_from_profile with the profile's own bench value beside it; roofline.traffic stays null."""
+def pmc_traffic(nb):
+    """HBM + Infinity-Cache bytes per step of the conv3x3 family from the newest COMMITTED rocprofv3 PMC summary that carries per-step
+    totals (profiles/*_pmc.json `per_step`, scripts/summarize_profile.py: every dispatch of the FETCH_SIZE (x2 per MI355X_MICROARCH.md)
+    and WRITE_SIZE passes of this same command at batch 64 in the default float32 configuration, summed and divided by the steps of
+    the pass).  NOT measured by this run (PMC counters need rocprofv3 around the process): `roofline.traffic` quotes it with
+    `traffic_source` naming the profile, and the profile's own bench value stands beside it."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files or nb != 64:
+    if nb != 64:
         return None
-    d = json.load(open(files[-1]))
-    # launches per step of each instantiation in the float32 default configuration (batch 64): 64-ch kernels run twice
-    # (grouped A|B pair + B3 alone); the Winograd blocks: in-transform x2, GEMM x2 per shape, one mid transform per
-    # block, one out-transform (AB2), one fused tail + finish (heads)
-    total = 0.0
-    wino_calls = {"wino_input_kernel": 2, "wino_gemm_kernel": 2, "wino_output_kernel": 1, "wino_mid_kernel": 1,
-                  "wino_tail_kernel": 1, "fc_finish_kernel": 1}
-    gemm_shape = ["1", "4", "3", "1"]          # 96 x 128 tiles (F(4x4) at batch 64)
-    if wino_on and wino_tile != 4:
-        # conv-by-conv form (F(6x6) / F(2x2)): in, GEMM, out per conv; per instantiation: the in-transform runs 4 x (2 per block), the
-        # GEMM 2 x per channel count, the out-transform 2 x per epilogue kind; then the separate tail kernel
-        if not any(k.startswith("wino_input_kernel<%d," % wino_tile) for k in d["fetch"]):
-            return None                          # the committed PMC summary is of another tile: no figure rather than a wrong one
-        wino_calls = {"wino_input_kernel": 4, "wino_gemm_kernel": 2, "wino_output_kernel": 2, "tail_kernel": 1}
-        gemm_shape = ["2", "2", "2", "2"]       # 128 x 128 tiles
-    for k, v in d["fetch"].items():
-        if k not in d["write"]:
-            continue
-        base = k.split("<")[0]
-        if base == "wino64_fused_kernel":   # <0> = conv1 (grouped A2|B2 + B3), <1> = conv2 with the residual: two launches each
-            if trunk_fused:
-                total += 2 * (2.0 * v["FETCH_SIZE"] + d["write"][k]["WRITE_SIZE"]) * 1024.0
-            continue
-        if base in wino_calls:
-            if not wino_on:
-                continue
-            if "<" in k:   # the f16x3 instantiations (last template argument SP / MM = 1) belong to the alt_precision leg
-                targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
-                if base in ("wino_input_kernel", "wino_output_kernel") and targs[0] != str(wino_tile):
-                    continue   # the other tile's transforms (alt legs of the profiled run)
-                if base == "wino_gemm_kernel" and targs[1:5] != gemm_shape:
-                    continue
-                nargs = {"wino_input_kernel": 3, "wino_output_kernel": 4, "wino_mid_kernel": 3, "wino_tail_kernel": 3, "wino_gemm_kernel": 6}
-                if len(targs) == nargs.get(base, -1) and targs[-1] == "1":
-                    continue
-            total += wino_calls[base] * (2.0 * v["FETCH_SIZE"] + d["write"][k]["WRITE_SIZE"]) * 1024.0
-            continue
-        if not k.startswith("conv3x3") or "<" not in k:
-            continue
-        targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
-        mm = targs[7] if k.startswith("conv3x3_slab") else targs[2]  # arithmetic mode template argument
-        if mm != "0":
-            continue  # the float32 instantiations only (the summary also holds the f16x3 ones)
-        if wino_on and k.startswith("conv3x3_slab") and targs[0] in ("256", "512"):
-            continue  # these layers ran as Winograd in the headline leg (the direct kernels are the alt_algorithm leg)
-        if trunk_fused and k.startswith("conv3x3_slab") and targs[0] == "64":
-            continue  # ran as the fused Winograd trunk kernel
-        calls = 2 if targs[0] == "64" else 1
-        total += calls * (2.0 * v["FETCH_SIZE"] + d["write"][k]["WRITE_SIZE"]) * 1024.0
-    tag = os.path.basename(files[-1]).replace("_pmc.json", "")
-    bench_value = None
-    bfile = os.path.join(ROOT, "profiles", tag + "_bench.json")
-    if os.path.isfile(bfile):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
-            bench_value = json.load(open(bfile)).get("value")
+            d = json.load(open(f))
         except Exception:   # noqa: BLE001
-            bench_value = None
-    return {"bytes_per_step": int(total), "source": "profiles/%s_pmc.json" % tag, "profile_bench_value": bench_value,
-            "algorithmic_bytes_per_step": nb * 991256 + 54100000,
-            "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE passes of a committed earlier run; "
-                    "includes Infinity-Cache hits"}
+            continue
+        ps = d.get("per_step")
+        if not ps:
+            continue
+        tag = os.path.basename(f).replace("_pmc.json", "")
+        bench_value = None
+        bfile = os.path.join(ROOT, "profiles", tag + "_bench.json")
+        if os.path.isfile(bfile):
+            try:
+                bench_value = json.load(open(bfile)).get("value")
+            except Exception:   # noqa: BLE001
+                bench_value = None
+        return {"bytes_per_step": int(ps["conv_family_bytes"]), "all_kernels_bytes_per_step": int(ps["all_kernels_bytes"]),
+                "source": "profiles/%s_pmc.json" % tag, "profile_bench_value": bench_value,
+                "algorithmic_bytes_per_step": nb * 991256 + 54100000,
+                "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE passes of a committed earlier run of this "
+                        "command; includes Infinity-Cache hits"}
+    return None
 
 
 def cpu_model():

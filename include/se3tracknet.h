@@ -99,18 +99,28 @@ size_t se3tn_split_weights_bytes(const se3tn_ctx* ctx);
 const void* se3tn_split_weights_device(const se3tn_ctx* ctx);
 int se3tn_split_weights_host(const void* packed_blob_host, size_t blob_bytes, void* out_split, size_t out_bytes);
 /* Algorithm of the stride-1 256/512-channel convolutions (AB2.*, trans|rot conv2.*) in
- * SE3TN_PREC_F32: batches of n >= min_batch pairs run them as Winograd F(tile x tile, 3x3), tile = 2 | 4 | 6 | AUTO
+ * SE3TN_PREC_F32: batches of n >= min_batch pairs run them as Winograd F(tile x tile, 3x3), tile = 2 | 4 | 6 | 6_4 | AUTO
  * (0 keeps the current tile) -- float32 MFMA GEMMs on (tile+2)^2 transformed planes, 2.25x / 4x / 5.06x fewer
  * multiplies per output; smaller batches and min_batch = 0 use the direct implicit-GEMM kernels.
  * All are float32 arithmetic and differ by rounding only (rms error of one layer relative to its
  * largest activation: direct 5e-8, tile 2 1.8e-7, tile 4 7e-7, tile 6 1.8e-6; end to end the logits move by
  * 0.5 / 0.6 / 1.4e-6 against the direct kernels) -- the same freedom cuDNN takes under
  * torch.backends.cudnn.benchmark = True in the reference (predict.py:78).  Tile 4 runs a whole residual block as one
- * fused launch sequence; tile 6 (64 planes: at batch 64 exactly two 128 x 128 GEMM tiles per workgroup slot, 21 % fewer
- * multiplies than tile 4) runs conv by conv and pays from 14 pairs on.  SE3TN_WINOGRAD_TILE_AUTO (the default) = tile 4 below
- * SE3TN_WINOGRAD_TILE6_MIN_BATCH pairs, tile 6 from there.  SE3TN_PREC_F16X3 has F(4x4) only and uses it whatever is selected. */
+ * fused launch sequence (in-transform, GEMM, [out | in] mid transform through LDS, GEMM, out-transform | fused avg-pool + FC tail);
+ * tile 6 (64 planes: at batch 64 exactly two 128 x 128 GEMM tiles per workgroup slot, 21 % fewer multiplies than tile 4) pays from
+ * 14 pairs on.  Where the rounding goes (batched 30-degree closed loop, 64 tracks, every pair against the CPU oracle,
+ * scripts/rounding_by_block.py): max |d logit| 4.9e-6 with tile 4 everywhere, 6.0e-6 with tile 6 on the 256-channel block only,
+ * 1.3e-5 with tile 6 on the 512-channel heads as well -- the heads' products go straight into the average pool + FC.
+ * SE3TN_WINOGRAD_TILE_6_4 = tile 6 for the 256-channel block, tile 4 for the heads.
+ * SE3TN_WINOGRAD_TILE_AUTO (the default): tile 4 below SE3TN_WINOGRAD_TILE6_MIN_BATCH pairs; from there tile 6 for the 256-channel
+ * block, and for the heads tile 6 while rot_normalizer (se3tn_set_normalizers) <= SE3TN_WINOGRAD_HEADS_TILE6_MAX_ROT, else tile 4: the
+ * rotation logits' rounding reaches the composed pose multiplied by rot_normalizer (tolerance 1e-5; with the reference's default
+ * 5 degrees the pose moves by < 1.2e-6 either way, with YCBInEOAT's 30 degrees by 3.1e-6 with tile 4 heads, 6.4e-6 with tile 6).
+ * SE3TN_PREC_F16X3 has F(4x4) only and uses it whatever is selected. */
 #define SE3TN_WINOGRAD_TILE_AUTO 46
+#define SE3TN_WINOGRAD_TILE_6_4 64
 #define SE3TN_WINOGRAD_TILE6_MIN_BATCH 14
+#define SE3TN_WINOGRAD_HEADS_TILE6_MAX_ROT 0.2   /* radians (11.5 degrees) */
 #define SE3TN_WINOGRAD_DEFAULT_MIN_BATCH 6
 #define SE3TN_WINOGRAD_DEFAULT_TILE SE3TN_WINOGRAD_TILE_AUTO
 int se3tn_set_winograd(se3tn_ctx* ctx, int min_batch, int tile);

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("SE3TN_LIB") or os.path.join(_HERE, "libse3tracknet.so
 NCHW, NHWC = 0, 1
 PREC_F32, PREC_F16X3 = 0, 1
 WINOGRAD_TILE_AUTO, WINOGRAD_TILE6_MIN_BATCH = 46, 14   # as include/se3tracknet.h: F(4x4) below 14 pairs, F(6x6) from there
+WINOGRAD_TILE_6_4, WINOGRAD_HEADS_TILE6_MAX_ROT = 64, 0.2     # F(6x6) 256-channel block + F(4x4) heads; AUTO's rot_normalizer bound for F(6x6) heads
 TRUNK_WINOGRAD_DEFAULT_MIN_BATCH, TRUNK_WINOGRAD_DEFAULT_MIN_FILL = 8, 55   # as include/se3tracknet.h (tests/test_host_abi.py)
 OFFSET_RULE_NUMPY1, OFFSET_RULE_NUMPY2 = 0, 1   # as include/se3tracknet.h: rounding of OffsetDepth's float64-scalar subtraction
 BLUR_NONE, BLUR_BILATERAL, BLUR_GAUSSIAN = 0, 1, 2

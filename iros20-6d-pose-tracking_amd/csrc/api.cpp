@@ -65,6 +65,8 @@ struct se3tn_ctx {
   float* logits = nullptr;                      // [mb,6]
   float* fcpart = nullptr;                      // [mb,2,8,3] partial FC dot products of the fused Winograd tail
   bool keep_intermediates = false;              // se3tn_keep_intermediates: fused blocks also store ab_t / head_t / head
+  int auto_tile_override[2] = {0, 0};           // SE3TN_WINOGRAD_AUTO_TILE_AB2 / _HEADS = 4 | 6: what AUTO picks per block (rounding studies)
+  bool wino_fuse = true;                        // whole residual blocks as one fused launch sequence (SE3TN_WINOGRAD_FUSE=0: conv by conv)
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
   size_t part_bytes = 0;
   // Winograd F(m x m,3x3) path (wino_mfma.hip) of convAB2.* and trans|rot conv2.* at n >= wino_min_batch
@@ -160,12 +162,19 @@ static size_t wino_ws_floats(int max_batch) {
 // and its fused head block on split operands) and pays from 14 pairs on (scripts/tile_sweep.sh: 0.511 vs 0.462 ms at n = 6, 0.701 vs
 // 0.718 at n = 16, 1.76 vs 1.86 at n = 64): SE3TN_WINOGRAD_TILE_AUTO switches there.  With tile 6 | AUTO selected both U sets are
 // resident: the F(4x4) planes in wino_u, the F(6x6) planes in wino_u6.
-static int tile_for(const se3tn_ctx* c, int n) {
+// which: 0 = the 256-channel block (convAB2), 1 = the 512-channel heads
+static int tile_for(const se3tn_ctx* c, int n, int which) {
   const int t = c->wino_tile;
   if (t == 2 || t == 4) return t;
   if (c->prec == SE3TN_PREC_F16X3) return 4;
   if (t == 6) return 6;
-  return n >= SE3TN_WINOGRAD_TILE6_MIN_BATCH ? 6 : 4;
+  if (t == SE3TN_WINOGRAD_TILE_6_4) return which == 0 ? 6 : 4;
+  if (c->auto_tile_override[which]) return c->auto_tile_override[which];   // developer switch: SE3TN_WINOGRAD_AUTO_TILE_AB2 / _HEADS
+  if (n < SE3TN_WINOGRAD_TILE6_MIN_BATCH) return 4;
+  // AUTO: F(6x6) where its rounding is cheap.  The heads' products feed the average pool + FC directly: F(6x6) there doubles the
+  // logits' rounding error (1.3e-5 vs 6.0e-6 in the batched 30-degree closed loop), and the rotation logits reach the composed pose
+  // multiplied by rot_normalizer -- with a large normaliser (YCBInEOAT's 30 degrees, predict.py:586) the heads stay on F(4x4)
+  return (which == 0 || c->rn <= SE3TN_WINOGRAD_HEADS_TILE6_MAX_ROT) ? 6 : 4;
 }
 static const ConvId kWino64Convs[4] = {L64_1, L64_2, L64_3, L64_4};
 static int wino64_prepare(se3tn_ctx* c, hipStream_t st) {
@@ -197,7 +206,8 @@ static int wino_prepare(se3tn_ctx* c, hipStream_t st) {
     }
   }
   const int tile = c->wino_tile == 2 ? 2 : 4;   // the planes in wino_u (tile 6 | AUTO keep the F(4x4) set there as well)
-  if (c->blob && (c->wino_tile == 6 || c->wino_tile == SE3TN_WINOGRAD_TILE_AUTO) && c->wino6_blob != c->blob) {
+  if (c->blob && (c->wino_tile == 6 || c->wino_tile == SE3TN_WINOGRAD_TILE_AUTO || c->wino_tile == SE3TN_WINOGRAD_TILE_6_4) &&
+      c->wino6_blob != c->blob) {
     for (int i = 0; i < 4; ++i) {
       const Conv3& s = conv_specs()[kWinoConvs[i]];
       if (!c->wino_u6[i]) HIPCHK(hipMalloc((void**)&c->wino_u6[i], (size_t)s.groups * 64 * s.cin * s.cout * sizeof(float)));
@@ -296,6 +306,10 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
   c->max_batch = max_batch;
   c->L = blob_layout();
   c->SL = split_layout();
+  if (const char* e = std::getenv("SE3TN_WINOGRAD_AUTO_TILE_AB2")) c->auto_tile_override[0] = (std::atoi(e) == 4 || std::atoi(e) == 6) ? std::atoi(e) : 0;
+  if (const char* e = std::getenv("SE3TN_WINOGRAD_AUTO_TILE_HEADS")) c->auto_tile_override[1] = (std::atoi(e) == 4 || std::atoi(e) == 6) ? std::atoi(e) : 0;
+  if (const char* e = std::getenv("SE3TN_WINOGRAD_FUSE")) c->wino_fuse = std::atoi(e) != 0;      // developer A/B switch (and the tests'
+                                                                                                  // bit-equality check of the two forms)
   if (const char* e = std::getenv("SE3TN_TRUNK_WINOGRAD")) c->wino64_min_batch = std::atoi(e);   // developer A/B switch
   if (const char* e = std::getenv("SE3TN_TRUNK_WINOGRAD_FILL")) c->wino64_min_fill = std::atoi(e);   // (scripts/trunk_sweep.sh)
   for (int i = 0; i < 8; ++i) { c->mean[i] = 0.0; c->stdv[i] = 1.0; }
@@ -436,8 +450,8 @@ int se3tn_bind_weights(se3tn_ctx* c, const void* device_blob, size_t bytes) {
 }
 
 int se3tn_set_winograd(se3tn_ctx* c, int min_batch, int tile) {
-  if (!c || min_batch < 0 || (tile != 0 && tile != 2 && tile != 4 && tile != 6 && tile != SE3TN_WINOGRAD_TILE_AUTO))
-    return fail(SE3TN_E_ARG, "se3tn_set_winograd: min_batch >= 0 and tile in {0, 2, 4, 6, SE3TN_WINOGRAD_TILE_AUTO}");
+  if (!c || min_batch < 0 || (tile != 0 && tile != 2 && tile != 4 && tile != 6 && tile != SE3TN_WINOGRAD_TILE_AUTO && tile != SE3TN_WINOGRAD_TILE_6_4))
+    return fail(SE3TN_E_ARG, "se3tn_set_winograd: min_batch >= 0 and tile in {0, 2, 4, 6, SE3TN_WINOGRAD_TILE_6_4, SE3TN_WINOGRAD_TILE_AUTO}");
   c->wino_min_batch = min_batch;
   if (tile) c->wino_tile = tile;
   if (c->device < 0) return SE3TN_OK;
@@ -595,15 +609,15 @@ static int prof_mark(se3tn_ctx* c, hipStream_t st, const char* name, bool is_con
 
 // Profile names say which ALGORITHM a launch took ("convAB2.conv1 [F(6x6)]"): the tests assert from them that the path they mean to
 // check is the one that ran.  Interned once per (name, tile); the strings live as long as the library.
-static const char* algo_name(const char* name, int tile) {
+static const char* algo_name(const char* name, int tile, bool fused_block = false) {
   static std::mutex mu;
   static std::map<std::pair<std::string, int>, std::string> names;
   std::lock_guard<std::mutex> lk(mu);
-  auto key = std::make_pair(std::string(name), tile);
+  auto key = std::make_pair(std::string(name), tile * 2 + (fused_block ? 1 : 0));
   auto it = names.find(key);
   if (it == names.end()) {
     const std::string t = std::to_string(tile);
-    it = names.emplace(key, std::string(name) + " [F(" + t + "x" + t + ")]").first;
+    it = names.emplace(key, std::string(name) + " [F(" + t + "x" + t + ")]" + (fused_block ? " fused block" : "")).first;
   }
   return it->second.c_str();
 }
@@ -720,7 +734,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
                   float* out, int out_ld, int out_gs, int hin, int stride, int epi, const char* name) -> int {
     const Conv3& s = conv_specs()[id];
     const int ws = wino_slot(id);
-    const int wtile = tile_for(c, n);
+    const int wtile = tile_for(c, n, ws >= 2 ? 1 : 0);
     const bool u_ready = wtile == 6 ? (c->wino_u6[0] && c->wino6_blob == c->blob) : (c->wino_tile_derived == wtile);
     if (ws >= 0 && !fast && c->wino_min_batch > 0 && n >= c->wino_min_batch && c->wino_v && u_ready) {
       WinoArgs w{};
@@ -733,6 +747,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
       w.C = s.cin; w.Cout = s.cout; w.groups = s.groups;
       w.in_gs = in_gs; w.res_gs = res_gs; w.out_gs = out_gs; w.bias_gs = s.cout;
       w.u_gs = (long long)w.nf * s.cin * s.cout;
+      w.num_cus = c->num_cus;
       hipError_t e = launch_wino_conv(w, epi, st);
       if (e != hipSuccess) return hipfail(e, name);
       return prof_mark(c, st, c->prof ? algo_name(name, wtile) : name, true);
@@ -771,27 +786,34 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
   if ((rc = conv(L64_3, c->q64 + 64, 128, 0, nullptr, 0, 0, c->t64 + 64, 128, 0, S2, 1, 0, "conv64 B3.conv1"))) return rc;
   if ((rc = conv(L64_4, c->t64 + 64, 128, 0, c->q64 + 64, 128, 0, c->q64 + 64, 128, 0, S2, 1, 1, "conv64 B3.conv2"))) return rc;
   if ((rc = conv(LAB1, c->q64, 128, 0, nullptr, 0, 0, c->ab, 256, 0, S2, 2, 2, "convAB1 s2"))) return rc;
-  // ResnetBasicBlocks of 256 / 512 channels: at n >= wino_min_batch with F(4x4) the whole block runs through
+  // ResnetBasicBlocks of 256 / 512 channels: at n >= wino_min_batch with F(4x4) or F(6x6) the whole block runs through
   // launch_wino_block (conv1's out-transform fused with conv2's in-transform; the heads' last out-transform fused
   // with avg-pool + FC + tanh); otherwise conv by conv (direct / split-K / F(2x2) kernels)
-  const bool wino_block = c->wino_min_batch > 0 && n >= c->wino_min_batch && c->wino_v && tile_for(c, n) == 4 && c->wino_tile_derived == 4 &&
-                          (!fast || (c->wino_us_blob == c->blob && c->wino_us_tile == 4));
+  auto block_ok = [&](int which) -> bool {
+    const int bt = tile_for(c, n, which);
+    const bool planes_ready = bt == 6 ? (!fast && c->wino_u6[0] && c->wino6_blob == c->blob) : (bt == 4 && c->wino_tile_derived == 4);
+    return c->wino_fuse && c->wino_min_batch > 0 && n >= c->wino_min_batch && c->wino_v && planes_ready &&
+           (!fast || (c->wino_us_blob == c->blob && c->wino_us_tile == 4));
+  };
   struct MarkCtx { se3tn_ctx* c; hipStream_t st; const char* name; };
   auto mark_fn = [](void* p) -> int { MarkCtx* m = (MarkCtx*)p; return prof_mark(m->c, m->st, m->name, true); };
   auto block = [&](ConvId id1, ConvId id2, float* io, float* mid, int ld, int gs, int hin, const TailArgs* tl,
                    const char* name1, const char* name2) -> int {
     const Conv3& s = conv_specs()[id1];
+    const int btile = tile_for(c, n, tl ? 1 : 0);
     WinoArgs w{};
-    w.in = io; w.U = c->wino_u[wino_slot(id1)]; w.bias = W + L.conv_b[id1]; w.res = nullptr; w.out = mid;
+    float* const* Uset = btile == 6 ? c->wino_u6 : c->wino_u;
+    w.in = io; w.U = Uset[wino_slot(id1)]; w.bias = W + L.conv_b[id1]; w.res = nullptr; w.out = mid;
     w.V = c->wino_v; w.Mw = c->wino_m;
     w.in_ld = ld; w.res_ld = ld; w.out_ld = ld;
-    w.m = 4; w.nf = 36;
-    w.H = hin; w.W = hin; w.th = (hin + 3) / 4; w.tw = w.th;
+    w.m = btile; w.nf = (btile + 2) * (btile + 2);
+    w.H = hin; w.W = hin; w.th = (hin + btile - 1) / btile; w.tw = w.th;
     w.n = n; w.T = n * w.th * w.tw;
     w.C = s.cin; w.Cout = s.cout; w.groups = s.groups;
     w.in_gs = gs; w.res_gs = gs; w.out_gs = gs; w.bias_gs = s.cout;
     w.u_gs = (long long)w.nf * s.cin * s.cout;
-    const float *U2 = c->wino_u[wino_slot(id2)], *usc2 = nullptr;
+    w.num_cus = c->num_cus;
+    const float *U2 = Uset[wino_slot(id2)], *usc2 = nullptr;
     float* keep2 = (tl && c->keep_intermediates) ? io : nullptr;
     if (fast) {   // f16x3: split-row activations / V / U, float32 M
       w.split = 1;
@@ -800,21 +822,21 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
       w.overflow = c->overflow;
       if (keep2) keep2 = c->head_f;   // the kept head activation is float32 (head itself holds split rows)
     }
-    MarkCtx mc{c, st, c->prof ? algo_name(name1, 4) : name1};
+    MarkCtx mc{c, st, c->prof ? algo_name(name1, btile, true) : name1};
     hipError_t e = launch_wino_block(w, U2, usc2, W + L.conv_b[id2], io, c->keep_intermediates ? 1 : 0, keep2, tl, st, mark_fn, &mc);
     if (e != hipSuccess) return hipfail(e, name2);
-    return prof_mark(c, st, c->prof ? algo_name(name2, 4) : name2, true);
+    return prof_mark(c, st, c->prof ? algo_name(name2, btile, true) : name2, true);
   };
   // f16x3 mode: the batched GEMMs of the 256-channel block are bandwidth-bound at the f16 matrix rate (41 FLOP per byte of V / M
   // traffic) and lose to the direct f16x3 kernels (0.247 vs 0.220 ms at batch 64); the 512-channel heads win (0.349 vs 0.427 ms)
-  if (wino_block && !fast) {
+  if (block_ok(0) && !fast) {
     if ((rc = block(LAB2_1, LAB2_2, c->ab, c->ab_t, 256, 0, S3, nullptr, "convAB2.conv1", "convAB2.conv2"))) return rc;
   } else {
     if ((rc = conv(LAB2_1, c->ab, 256, 0, nullptr, 0, 0, c->ab_t, 256, 0, S3, 1, 0, "convAB2.conv1"))) return rc;
     if ((rc = conv(LAB2_2, c->ab_t, 256, 0, c->ab, 256, 0, c->ab, 256, 0, S3, 1, 1, "convAB2.conv2"))) return rc;
   }
   if ((rc = conv(LH1, c->ab, 256, 0, nullptr, 0, 0, c->head, 1024, 0, S3, 2, 2, "trans|rot conv1 s2"))) return rc;
-  if (wino_block) {
+  if (block_ok(1)) {
     TailArgs tl{W + L.fc_w, W + L.fc_b, c->logits, c->fcpart, trans, rot, poseA, poseB, c->tn, c->rn};
     if ((rc = block(LH2_1, LH2_2, c->head, c->head_t, 1024, 512, S4, &tl, "trans|rot conv2.conv1",
                     "trans|rot conv2.conv2 + avgpool+fc+tanh+pose"))) return rc;

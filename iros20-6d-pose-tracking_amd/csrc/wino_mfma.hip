@@ -26,6 +26,7 @@
 // (tests/test_gpu_parity.py::test_winograd_*).
 #include "mfma_common.h"
 #include "pose_device.h"
+#include <cstdlib>
 
 #ifndef WINO4_VEC
 #define WINO4_VEC 2  // channels per thread of the F(4x4) transform kernels (2: 8-byte, 4: 16-byte accesses; measured equal)
@@ -606,6 +607,139 @@ __global__ __launch_bounds__(512, 2) void wino_gemm8_kernel(const WinoArgs a) {
 }
 
 
+// -------------------------------------------------------------------------------------------------
+// wino_gemmp_kernel ("p" = persistent): 128 rows x 256 couts per tile, EIGHT waves (2 x 4, each 64 x 64 = 2 x 2 blocks), one
+// workgroup per CU that walks tiles v = w, w + G, ... without leaving its K-loop: the first chunk of the NEXT tile is DMA'd during the
+// last K-step of the current one, the accumulators are stored (fire and forget) between two K-steps, so a tile boundary costs the
+// store issue only -- no prologue, no drained pipeline, whatever the K length (K = 256 is 8 K-steps per tile).
+// Why this shape: with F(6x6) a batch-64 launch is exactly 512 of these tiles = 2.0 per CU for BOTH layer shapes
+// (1024 x 256 x 64 planes and 2 x 256 x 512 x 64), a V row tile is fetched once for all its couts (AB2) and the per-K-step DMA is
+// 48 KB per 128 x 256 x 32 MACs where two co-resident 128 x 128 workgroups move 64 KB.
+// Tile order: virtual tile v runs on XCD v % 8 (observed dispatch: workgroup w on XCD w % 8; speed only); the tiles of one plane
+// b = (group, frequency) are consecutive slots of ONE XCD, so U_b and V_b cross that XCD's L2 once.
+// Same fragment layout, swizzle and k order as wino_gemm_kernel: bit-identical M.
+// -------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(512, 2) void wino_gemmp_kernel(const WinoArgs a, int total_tiles) {
+  constexpr int PT = 2, CT = 2, BM = 128, BN = 256;
+  constexpr int NCH = CIN / 32;
+  constexpr int BUF = (BM + BN) * 32;
+  static_assert(NCH % 2 == 0, "the double buffer's parity must be the same at every tile start");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int panels = a.Cout / BN, mtiles = (a.T + BM - 1) / BM, tpp = panels * mtiles;
+  const int mlast = a.T - 1;
+
+  // staging: thread t fills LDS slot (t & 7) of rows (t >> 3) + 64 j with channel block (t & 7) ^ ((row >> 1) & 7)
+  const int r0 = tid >> 3;
+  const int c4 = (tid & 7) ^ ((r0 >> 1) & 7);
+  const unsigned wvoff = (unsigned)((r0 * 32 + c4 * 4) * 4);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+  // virtual tile -> (plane b, row tile, cout panel)
+  auto decode = [&](int v, int& b, int& m0, int& n0) {
+    const int xcd = v & 7, s = v >> 3;
+    const int q = s / tpp, r = s - q * tpp;
+    b = q * 8 + xcd;
+    n0 = (r % panels) * BN;
+    m0 = (r / panels) * BM;
+  };
+  const float* Vb;
+  const float* Ub;
+  unsigned pvoff[2];
+  auto set_tile = [&](int b, int m0, int n0) {
+    const int g = b / a.nf, f = b - g * a.nf;
+    Vb = a.V + (size_t)b * a.T * CIN;
+    Ub = a.U + (size_t)g * a.u_gs + ((size_t)f * a.Cout + n0) * 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pvoff[j] = (unsigned)((min(m0 + r0 + 64 * j, mlast) * CIN + c4 * 4) * 4);
+  };
+#define ISSUE_TILEP(CH, BUFI)                                                                        \
+  {                                                                                                  \
+    const float* pb_ = Vb + (CH) * 32;                                                               \
+    const unsigned lb_ = lds0 + (unsigned)(((BUFI) * BUF + wid * 256) * 4);                          \
+    glds16<0>(pb_, pvoff[0], lb_);                                                                   \
+    glds16<0>(pb_, pvoff[1], lb_ + 8192);                                                            \
+    const float* tb_ = Ub + (size_t)(CH) * a.nf * a.Cout * 32;                                       \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) glds16<0>(tb_ + 2048 * j_, wvoff, lb_ + BM * 128 + j_ * 8192); \
+  }
+
+  const int X = (l31 >> 1) & 7;
+  const int lo = (hh ^ (X & 1)) * 4, xk = X >> 1;
+  const int fo0 = ((0 ^ xk) << 3) + lo, fo1 = ((1 ^ xk) << 3) + lo, fo2 = ((2 ^ xk) << 3) + lo, fo3 = ((3 ^ xk) << 3) + lo;
+
+  f32x16 acc[PT][CT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int v = blockIdx.x;
+  if (v >= total_tiles) return;
+  int b, m0, n0;
+  decode(v, b, m0, n0);
+  set_tile(b, m0, n0);
+  ISSUE_TILEP(0, 0)
+  wait_dma_and_barrier();
+
+  while (true) {
+    const int vn = v + gridDim.x;
+    const bool more = vn < total_tiles;
+    const int cb = b, cm0 = m0, cn0 = n0;   // the tile whose accumulators are being formed
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int buf = ch & 1;
+      if (ch + 1 < NCH) {
+        ISSUE_TILEP(ch + 1, buf ^ 1)
+      } else if (more) {   // the next tile's first chunk rides under this tile's last K-step
+        decode(vn, b, m0, n0);
+        set_tile(b, m0, n0);
+        ISSUE_TILEP(0, buf ^ 1)
+      }
+      const float* pP = smem + buf * BUF + (wm * PT * 32 + l31) * 32;
+      const float* pW = smem + buf * BUF + (BM + wn * CT * 32 + l31) * 32;
+#define FOG(G) ((G) == 0 ? fo0 : (G) == 1 ? fo1 : (G) == 2 ? fo2 : fo3)
+#define PXF(G) *reinterpret_cast<const float4*>(pP + i * 1024 + FOG(G))
+#define WTF(G) *reinterpret_cast<const float4*>(pW + j * 1024 + FOG(G))
+      SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
+      SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
+      SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
+      SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
+#undef PXF
+#undef WTF
+#undef FOG
+      if (ch + 1 < NCH || more) wait_dma_and_barrier();
+    }
+    // lane holds row l31 x couts {8 q + 4 hh + 0..3} of each 32 x 32 block; the stores drain under the next tile's first K-step
+    float* __restrict__ Mb = a.Mw + (size_t)cb * a.T * a.Cout;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int m = cm0 + (wm * PT + i) * 32 + l31;
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = cn0 + (wn * CT + j) * 32 + q * 8 + hh * 4;
+          if (m <= mlast)
+            *reinterpret_cast<float4*>(Mb + (size_t)m * a.Cout + c) =
+                make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = 0.f;
+        }
+    }
+    if (!more) break;
+    v = vn;
+  }
+#undef ISSUE_TILEP
+}
+
 // =================================================================================================
 // Block-level fusions of the F(4x4) path (a ResnetBasicBlock = conv1+BN+ReLU, conv2+BN, +x, ReLU;
 // network_modules.py:103-120).  Both remove a full write + read of an activation tensor between two
@@ -619,9 +753,17 @@ __global__ __launch_bounds__(512, 2) void wino_gemm8_kernel(const WinoArgs a) {
 //                     one head, the 11 x 11 x 512 activation is reduced in registers and never stored
 //                     (again unless asked for).  The float64 pose update follows in pose_update_kernel.
 // =================================================================================================
-template <int TH, int CS, int SP = 0>
-__global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_mid_kernel(const WinoArgs a, float* __restrict__ keep) {
-  constexpr int M = 4, N = 6, HP = 4 * TH + 2, NT = TH * TH, CP = CS / 2, ITEMS = NT * CP;
+template <> struct VecT<1> { typedef float type; };
+
+// M = 4 | 6 (the output tile edge), TH x TH tiles per image, CS channels per workgroup, VEC channels per thread.
+// F(6x6): 22 x 22 maps = 4 x 4 tiles, 11 x 11 = 2 x 2; the padded activation the two phases share has the same 26 x 26 / 14 x 14
+// pixels as F(4x4)'s (M TH + 2).  Same operations in the same order as wino_output_kernel<M> followed by wino_input_kernel<M>:
+// the fused and the conv-by-conv form give identical bits (tests/test_gpu_parity.py).
+template <int M, int TH, int CS, int VEC, int SP = 0>
+__global__ __launch_bounds__(((TH * TH * (CS / VEC) + 63) / 64) * 64) void wino_mid_kernel(const WinoArgs a, float* __restrict__ keep) {
+  constexpr int N = M + 2, HP = M * TH + 2, NT = TH * TH, CP = CS / VEC, ITEMS = NT * CP;
+  typedef typename VecT<VEC>::type vec;
+  static_assert(SP == 0 || (M == 4 && VEC == 2), "the f16x3 blocks are F(4x4) with channel pairs");
   extern __shared__ __attribute__((aligned(16))) float act[];  // [HP][HP][CS], padded coordinates
   const int n = blockIdx.x, c0 = blockIdx.y * CS, g = blockIdx.z;
   const int tid = threadIdx.x;
@@ -633,21 +775,21 @@ __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_mi
   const int t = n * NT + tile;
   const int Hp = a.H + 2, Wp = a.W + 2;
   if (active) {
-    const float* __restrict__ src = a.Mw + ((size_t)g * a.nf * a.T + t) * a.Cout + c0 + cp * 2;
+    const float* __restrict__ src = a.Mw + ((size_t)g * a.nf * a.T + t) * a.Cout + c0 + cp * VEC;
     const size_t fs = (size_t)a.T * a.Cout;
-    float u[M][N][2];
+    float u[M][N][VEC];
 #pragma unroll
     for (int s = 0; s < N; ++s) {
-      float m[N][2];
+      float m[N][VEC];
 #pragma unroll
       for (int r = 0; r < N; ++r) {
-        const float2 v = *reinterpret_cast<const float2*>(src + (size_t)(N * r + s) * fs);
-        m[r][0] = v.x; m[r][1] = v.y;
+        const vec v = *reinterpret_cast<const vec*>(src + (size_t)(N * r + s) * fs);
+        __builtin_memcpy(m[r], &v, sizeof(v));
       }
 #pragma unroll
       for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < VEC; ++e) {
           float acc = 0.f;
           bool first = true;
 #pragma unroll
@@ -655,42 +797,49 @@ __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_mi
           u[i][s][e] = acc;
         }
     }
-    const float2 b = *reinterpret_cast<const float2*>(a.bias + (size_t)g * a.bias_gs + c0 + cp * 2);
-    float* __restrict__ kp = keep ? keep + (size_t)g * a.out_gs + c0 + cp * 2 : nullptr;
+    float b[VEC];
+    {
+      const vec v = *reinterpret_cast<const vec*>(a.bias + (size_t)g * a.bias_gs + c0 + cp * VEC);
+      __builtin_memcpy(b, &v, sizeof(v));
+    }
+    float* __restrict__ kp = keep ? keep + (size_t)g * a.out_gs + c0 + cp * VEC : nullptr;
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
       for (int j = 0; j < M; ++j) {
         const int oy = M * ty + i, ox = M * tx + j;
         if (oy >= a.H || ox >= a.W) continue;
-        float o[2];
+        float o[VEC];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < VEC; ++e) {
           float acc = 0.f;
           bool first = true;
 #pragma unroll
           for (int s = 0; s < N; ++s) axpy(acc, wino_at<M>(j, s), u[i][s][e], first);
-          o[e] = fmaxf(acc + (e ? b.y : b.x), 0.f);
+          acc += b[e];
+          o[e] = fmaxf(acc, 0.f);
         }
-        *reinterpret_cast<float2*>(act + ((oy + 1) * HP + ox + 1) * CS + cp * 2) = make_float2(o[0], o[1]);
-        if (kp) *reinterpret_cast<float2*>(kp + (size_t)((n * Hp + oy + 1) * Wp + ox + 1) * a.out_ld) = make_float2(o[0], o[1]);
+        vec v;
+        __builtin_memcpy(&v, o, sizeof(v));
+        *reinterpret_cast<vec*>(act + ((oy + 1) * HP + ox + 1) * CS + cp * VEC) = v;
+        if (kp) *reinterpret_cast<vec*>(kp + (size_t)((n * Hp + oy + 1) * Wp + ox + 1) * a.out_ld) = v;
       }
   }
   __syncthreads();
   if (active) {
-    float bt[N][N][2];  // B^T d, one column s at a time
+    float bt[N][N][VEC];  // B^T d, one column s at a time
 #pragma unroll
     for (int s = 0; s < N; ++s) {
-      float d[N][2];
+      float d[N][VEC];
 #pragma unroll
       for (int r = 0; r < N; ++r) {
-        const float2 v = *reinterpret_cast<const float2*>(act + ((M * ty + r) * HP + M * tx + s) * CS + cp * 2);
-        d[r][0] = v.x; d[r][1] = v.y;
+        const vec v = *reinterpret_cast<const vec*>(act + ((M * ty + r) * HP + M * tx + s) * CS + cp * VEC);
+        __builtin_memcpy(d[r], &v, sizeof(v));
       }
 #pragma unroll
       for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < VEC; ++e) {
           float acc = 0.f;
           bool first = true;
 #pragma unroll
@@ -698,24 +847,29 @@ __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_mi
           bt[i][s][e] = acc;
         }
     }
-    float* __restrict__ dst = a.V + ((size_t)g * a.nf * a.T + t) * a.C + (SP ? 0 : c0 + cp * 2);
+    float* __restrict__ dst = a.V + ((size_t)g * a.nf * a.T + t) * a.C + (SP ? 0 : c0 + cp * VEC);
     const size_t fs = (size_t)a.T * a.C;
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        float o[2];
+        float o[VEC];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < VEC; ++e) {
           float acc = 0.f;
           bool first = true;
 #pragma unroll
           for (int s = 0; s < N; ++s) axpy(acc, wino_bt<M>(j, s), bt[i][s][e], first);
           o[e] = acc;
         }
-        if (SP) bad |= store_split_vec<2>(dst + (size_t)(N * i + j) * fs, 0, a.C, c0 + cp * 2, o);
-        else *reinterpret_cast<float2*>(dst + (size_t)(N * i + j) * fs) = make_float2(o[0], o[1]);
+        if constexpr (SP != 0) {
+          bad |= store_split_vec<VEC>(dst + (size_t)(N * i + j) * fs, 0, a.C, c0 + cp * VEC, o);
+        } else {
+          vec v;
+          __builtin_memcpy(&v, o, sizeof(v));
+          *reinterpret_cast<vec*>(dst + (size_t)(N * i + j) * fs) = v;
+        }
       }
     if (SP && bad) atomicOr(a.overflow, 1);
   }
@@ -731,11 +885,12 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // same parallelism; the per-channel sums over the map are reduced through LDS in a fixed order, each workgroup
 // contributes the partial dot products of its CS channels with the head's three FC rows:
 // fcpart[n][head][slice][3].  fc_finish_kernel adds the slices (fixed order), the bias, applies tanh and the pose update.
-template <int TH, int CS, int SP = 0>
+template <int M, int TH, int CS, int SP = 0>
 __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_tail_kernel(const WinoArgs a, float* __restrict__ keep,
                                                                                          const float* __restrict__ fc_w,
                                                                                          float* __restrict__ fcpart) {
-  constexpr int M = 4, N = 6, NT = TH * TH, CP = CS / 2, ITEMS = NT * CP;
+  constexpr int N = M + 2, NT = TH * TH, CP = CS / 2, ITEMS = NT * CP;
+  static_assert(SP == 0 || M == 4, "the f16x3 blocks are F(4x4)");
   static_assert(CP == 32, "the FC partials are reduced inside one half-wave");
   __shared__ float red[NT][CP][2];
   const int n = blockIdx.x, sl = blockIdx.y, g = blockIdx.z, tid = threadIdx.x;
@@ -892,6 +1047,24 @@ static hipError_t launch_gemm8(const WinoArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <int CIN>
+static hipError_t launch_gemmp(const WinoArgs& a, int total_tiles, int grid, hipStream_t st) {
+  static PerDeviceOnce attr;
+  auto kern = wino_gemmp_kernel<CIN>;
+  const size_t lds = 2 * (128 + 256) * 32 * sizeof(float);
+  bool* done = attr.current();
+  if (!done || !*done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (done) *done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);
+  return hipGetLastError();
+}
+
+#ifndef SE3TN_WINO_GEMMP
+#define SE3TN_WINO_GEMMP 1   // 0: never take the persistent 128 x 256 kernel
+#endif
 #ifndef SE3TN_WINO_GEMM8
 #define SE3TN_WINO_GEMM8 0   // 1: 96-row tiles run as 8-wave workgroups with intra-workgroup split-K (wino_gemm8_kernel)
 #endif
@@ -902,6 +1075,14 @@ static hipError_t launch_gemm_auto(const WinoArgs& a, hipStream_t st) {
   const long long q128 = ((((a.T + 127) / 128) * per_b + 255) / 256) * 16;
   const long long q96 = ((((a.T + 95) / 96) * per_b + 255) / 256) * 12;
   if (a.split) return q96 < q128 ? launch_gemm<CIN, 1, 4, 3, 1, MM_F16X3>(a, st) : launch_gemm<CIN, 2, 2, 2, 2, MM_F16X3>(a, st);
+  // persistent 128 x 256 tiles, one 8-wave workgroup per CU: when they fill every CU at least twice (F(6x6) at batch 64: exactly 2.0)
+  // and the plane count lets the XCD-local tile order cover them (groups nf % 8 == 0: 36 F(4x4) planes do not)
+  if (SE3TN_WINO_GEMMP && a.Cout % 256 == 0 && (a.groups * a.nf) % 8 == 0) {
+    const int cus = a.num_cus > 0 ? a.num_cus : 256;
+    const int tiles = (a.Cout / 256) * ((a.T + 127) / 128) * a.groups * a.nf;
+    static const int force = std::getenv("SE3TN_WINO_GEMMP") ? std::atoi(std::getenv("SE3TN_WINO_GEMMP")) : -1;   // developer A/B switch
+    if (force != 0 && (force == 1 || tiles >= 2 * cus)) return launch_gemmp<CIN>(a, tiles, tiles < cus ? tiles : (cus / 8) * 8, st);
+  }
   if (SE3TN_WINO_GEMM8 && q96 < q128) return launch_gemm8<CIN>(a, st);
   return q96 < q128 ? launch_gemm<CIN, 1, 4, 3, 1>(a, st) : launch_gemm<CIN, 2, 2, 2, 2>(a, st);
 }
@@ -924,12 +1105,12 @@ static hipError_t launch_transformed(const WinoArgs& a, int epi, hipStream_t st)
 // the out-transform with the residual epilogue or (tl != nullptr, the heads' last block) the fused
 // out-transform + avg-pool + FC + tanh.  c1 describes conv1 (in = block input, out = the intermediate activation
 // buffer, only written if keep_mid); conv2 reads the same V / Mw workspaces, residual = c1.in, output = out2.
-template <int TH, int CS, int SP = 0>
+template <int M, int TH, int CS, int VEC, int SP = 0>
 static hipError_t launch_mid(const WinoArgs& a, float* keep, hipStream_t st) {
-  constexpr int HP = 4 * TH + 2, THREADS = ((TH * TH * (CS / 2) + 63) / 64) * 64;
+  constexpr int HP = M * TH + 2, THREADS = ((TH * TH * (CS / VEC) + 63) / 64) * 64;
   constexpr size_t lds = (size_t)HP * HP * CS * sizeof(float);
   static PerDeviceOnce attr;
-  auto kern = wino_mid_kernel<TH, CS, SP>;
+  auto kern = wino_mid_kernel<M, TH, CS, VEC, SP>;
   bool* done = attr.current();
   if (!done || !*done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -940,35 +1121,55 @@ static hipError_t launch_mid(const WinoArgs& a, float* keep, hipStream_t st) {
   return hipGetLastError();
 }
 
+#ifndef WINO6_MID_VEC
+#define WINO6_MID_VEC 1    // channels per thread of the F(6x6) mid transform: 1 = 512 threads on the 22 x 22 maps (8 waves per CU beside
+#endif                     // 86 KB of LDS), 2 = 256
+#ifndef WINO6_MID_CS_H
+#define WINO6_MID_CS_H 64  // channels per workgroup of the F(6x6) mid transform on the 11 x 11 maps (LDS 14 x 14 x CS floats)
+#endif
+
 hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* uscale2, const float* bias2, float* out2, int keep_mid,
                              float* keep_out2, const TailArgs* tl, hipStream_t st, int mark_after_mid(void*), void* mark_ctx) {
-  if (c1.m != 4 || c1.nf != 36 || c1.C != c1.Cout || (c1.C != 256 && c1.C != 512)) return hipErrorInvalidValue;
-  if (!((c1.th == 6 && c1.C == 256) || (c1.th == 3 && c1.C == 512)) || c1.tw != c1.th) return hipErrorInvalidValue;
-  const dim3 ig((c1.T * (c1.C / WINO4_VEC) + 255) / 256, c1.groups);
-  if (c1.split) hipLaunchKernelGGL((wino_input_kernel<4, WINO4_VEC, 1>), ig, dim3(256), 0, st, c1);
-  else hipLaunchKernelGGL((wino_input_kernel<4, WINO4_VEC>), ig, dim3(256), 0, st, c1);
+  if ((c1.m != 4 && c1.m != 6) || c1.nf != (c1.m + 2) * (c1.m + 2) || c1.C != c1.Cout || (c1.C != 256 && c1.C != 512))
+    return hipErrorInvalidValue;
+  const int th_ab = c1.m == 4 ? 6 : 4, th_h = c1.m == 4 ? 3 : 2;
+  if (!((c1.th == th_ab && c1.C == 256) || (c1.th == th_h && c1.C == 512)) || c1.tw != c1.th) return hipErrorInvalidValue;
+  if (c1.m == 6 && c1.split) return hipErrorInvalidValue;   // F(6x6) is a float32 path
+  const bool ab = c1.C == 256;
+  if (c1.m == 6) {
+    hipLaunchKernelGGL((wino_input_kernel<6, 2>), dim3((c1.T * (c1.C / 2) + 255) / 256, c1.groups), dim3(256), 0, st, c1);
+  } else {
+    const dim3 ig((c1.T * (c1.C / WINO4_VEC) + 255) / 256, c1.groups);
+    if (c1.split) hipLaunchKernelGGL((wino_input_kernel<4, WINO4_VEC, 1>), ig, dim3(256), 0, st, c1);
+    else hipLaunchKernelGGL((wino_input_kernel<4, WINO4_VEC>), ig, dim3(256), 0, st, c1);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  e = c1.C == 256 ? launch_gemm_auto<256>(c1, st) : launch_gemm_auto<512>(c1, st);
+  e = ab ? launch_gemm_auto<256>(c1, st) : launch_gemm_auto<512>(c1, st);
   if (e != hipSuccess) return e;
   float* keep1 = keep_mid ? c1.out : nullptr;
-  if (c1.split) e = c1.th == 6 ? launch_mid<6, WINO_MID_CS_AB, 1>(c1, keep1, st) : launch_mid<3, WINO_MID_CS_H, 1>(c1, keep1, st);
-  else e = c1.th == 6 ? launch_mid<6, WINO_MID_CS_AB>(c1, keep1, st) : launch_mid<3, WINO_MID_CS_H>(c1, keep1, st);
+  if (c1.m == 6) e = ab ? launch_mid<6, 4, 32, WINO6_MID_VEC>(c1, keep1, st) : launch_mid<6, 2, WINO6_MID_CS_H, WINO6_MID_VEC>(c1, keep1, st);
+  else if (c1.split) e = ab ? launch_mid<4, 6, WINO_MID_CS_AB, 2, 1>(c1, keep1, st) : launch_mid<4, 3, WINO_MID_CS_H, 2, 1>(c1, keep1, st);
+  else e = ab ? launch_mid<4, 6, WINO_MID_CS_AB, 2>(c1, keep1, st) : launch_mid<4, 3, WINO_MID_CS_H, 2>(c1, keep1, st);
   if (e != hipSuccess) return e;
   if (mark_after_mid && mark_after_mid(mark_ctx)) return hipErrorUnknown;
   WinoArgs c2 = c1;
   c2.U = U2; c2.uscale = uscale2; c2.bias = bias2; c2.res = c1.in; c2.res_ld = c1.in_ld; c2.res_gs = c1.in_gs; c2.out = out2;
-  e = c1.C == 256 ? launch_gemm_auto<256>(c2, st) : launch_gemm_auto<512>(c2, st);
+  e = ab ? launch_gemm_auto<256>(c2, st) : launch_gemm_auto<512>(c2, st);
   if (e != hipSuccess) return e;
   if (tl) {
-    if (c1.th != 3 || c1.groups != 2 || c1.Cout != 512) return hipErrorInvalidValue;
-    constexpr int CS = 64, THREADS = ((9 * (CS / 2) + 63) / 64) * 64;
-    if (c1.split) hipLaunchKernelGGL((wino_tail_kernel<3, CS, 1>), dim3(c1.n, 512 / CS, 2), dim3(THREADS), 0, st, c2, keep_out2, tl->fc_w, tl->fcpart);
-    else hipLaunchKernelGGL((wino_tail_kernel<3, CS>), dim3(c1.n, 512 / CS, 2), dim3(THREADS), 0, st, c2, keep_out2, tl->fc_w, tl->fcpart);
+    if (ab || c1.groups != 2 || c1.Cout != 512) return hipErrorInvalidValue;
+    constexpr int CS = 64;
+    const dim3 tg(c1.n, 512 / CS, 2);
+    if (c1.m == 6) hipLaunchKernelGGL((wino_tail_kernel<6, 2, CS>), tg, dim3(((4 * (CS / 2) + 63) / 64) * 64), 0, st, c2, keep_out2, tl->fc_w, tl->fcpart);
+    else if (c1.split) hipLaunchKernelGGL((wino_tail_kernel<4, 3, CS, 1>), tg, dim3(((9 * (CS / 2) + 63) / 64) * 64), 0, st, c2, keep_out2, tl->fc_w, tl->fcpart);
+    else hipLaunchKernelGGL((wino_tail_kernel<4, 3, CS>), tg, dim3(((9 * (CS / 2) + 63) / 64) * 64), 0, st, c2, keep_out2, tl->fc_w, tl->fcpart);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fc_finish_kernel, dim3((c1.n + 9) / 10), dim3(64), 0, st, tl->fcpart, 512 / CS, *tl, tl->poseA, tl->poseB,
                        tl->tn, tl->rn, c1.n);
+  } else if (c1.m == 6) {
+    hipLaunchKernelGGL((wino_output_kernel<6, 2, 1>), dim3((c2.T * (c2.Cout / 2) + 255) / 256, c2.groups), dim3(256), 0, st, c2);
   } else {
     const dim3 og((c2.T * (c2.Cout / WINO4_VEC) + 255) / 256, c2.groups);
     if (c1.split) hipLaunchKernelGGL((wino_output_kernel<4, WINO4_VEC, 1, 1>), og, dim3(256), 0, st, c2);

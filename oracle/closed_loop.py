@@ -172,14 +172,17 @@ def run_regime(se3, regime, frames=300, check=True, subdiv=5, precision=None, ti
     return out
 
 
-def run_regime_batch(se3, regime, tracks, frames=50, subdiv=4, winograd=None):
+def run_regime_batch(se3, regime, tracks, frames=50, subdiv=4, winograd=None, compare=()):
     """`tracks` INDEPENDENT closed-loop tracks advanced together through ``Tracker.on_track_batch`` (one engine call of n = tracks
     pairs per frame): the configuration where the large-batch algorithms of the library -- Winograd F(6x6) blocks from 14 pairs,
     the fused trunk kernel in whole rounds of workgroups -- meet the binding tolerance (30-degree normaliser: a logit error is
     amplified 6 x into the pose, 1e-5).  Track k starts from its own pose, follows the anchor trajectory with its own phase and
     reads the frame sequence with its own offset; every pair of every frame is checked against the oracle (network forward
     batched over the tracks, everything else per pair) fed the image A the HIP rasteriser rendered for that pair.
-    Returns the per-regime block of run_regime plus `launches`: the 256/512-channel conv launches of one profiled frame."""
+    `compare`: other algorithm settings, as (name, (winograd min_batch, tile), (trunk min_batch, fill)) -- every frame's input
+    buffers are run through the engine again under each of them (no feedback) and the logits compared with the same oracle
+    logits: `alt_max_abs_logit_diff[name]`, the like-for-like figure of what an algorithm choice costs in rounding.
+    Returns the per-regime block of run_regime plus `launches`: the conv launches of one profiled frame."""
     import torch
     seq = _frames()
     trk, sd, (mean, std), nfaces = make_tracker(se3, subdiv, None, regime, seq, max_samples=tracks)
@@ -198,6 +201,7 @@ def run_regime_batch(se3, regime, tracks, frames=50, subdiv=4, winograd=None):
     e_net = e_pose = e_logit = 0.0
     outs, bboxes = [], []
     launches = None
+    alt_err = {}
     for f in range(frames):
         rgbs = [seq[(f + foff[k]) % N_DISTINCT_FRAMES][0] for k in range(n)]
         deps = [seq[(f + foff[k]) % N_DISTINCT_FRAMES][1] for k in range(n)]
@@ -206,7 +210,7 @@ def run_regime_batch(se3, regime, tracks, frames=50, subdiv=4, winograd=None):
         Q = trk.on_track_batch(P, rgbs, deps)
         if f == 1:
             torch.cuda.synchronize()
-            launches = [nm for nm, _ in trk.engine.profile_launches(0) if nm.startswith("conv")]
+            launches = [nm for nm, _ in trk.engine.profile_launches(0) if nm.startswith("conv") or nm.startswith("trans|rot")]
             trk.engine.profile_enable(0)
         lg = trk.engine.logits(n).cpu().numpy()
         lp = trk.last_prediction
@@ -228,6 +232,14 @@ def run_regime_batch(se3, regime, tracks, frames=50, subdiv=4, winograd=None):
             bboxes.append(bbs[k].reshape(-1))
         e_net = max(e_net, float(np.abs(np.c_[lp["trans"], lp["rot"]] - np.c_[rt, rr]).max()))
         e_logit = max(e_logit, float(np.abs(lg - rl).max()))
+        if compare:
+            eng = trk.engine
+            w0, t0 = eng.get_winograd(), eng.get_trunk_winograd()
+            for name, w, t in compare:
+                eng.set_winograd(*w); eng.set_trunk_winograd(*t)
+                eng.infer(eng.input_buffer_ptr(0), eng.input_buffer_ptr(1), n, se3.NHWC)
+                alt_err[name] = max(alt_err.get(name, 0.0), float(np.abs(eng.logits(n).cpu().numpy() - rl).max()))
+            eng.set_winograd(*w0); eng.set_trunk_winograd(*t0)
         outs.append(np.c_[rt, rr])
         for k in range(n):
             N = Q[k].copy()
@@ -244,6 +256,7 @@ def run_regime_batch(se3, regime, tracks, frames=50, subdiv=4, winograd=None):
            "median_abs_trans_rot": round(float(np.median(np.abs(signed))), 4),
            "std_trans_rot": [round(float(v), 4) for v in signed.std(0)],
            "max_abs_output": round(float(np.abs(signed).max()), 4), "reinits": reinits, "launches": launches,
+           "alt_max_abs_logit_diff": alt_err,
            "ok": bool(bbox_mismatch == 0 and e_net <= 1e-4 and e_logit <= 1e-4 and e_pose <= 1e-5)}
     return out
 

@@ -57,7 +57,35 @@ def pmc(sub):
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 
 
+def pmc_totals(sub, counter):
+    """Per-kernel SUM of a counter over every dispatch of the pass + the number of dispatches (for per-step figures)."""
+    p = os.path.join(src, sub, "pmc_counter_collection.csv")
+    tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    if os.path.exists(p):
+        for r in csv.DictReader(open(p)):
+            if "se3tn::" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                tot[short(r["Kernel_Name"])] += float(r["Counter_Value"])
+                cnt[short(r["Kernel_Name"])] += 1
+    return tot, cnt
+
+
 sq, lds, fe, wr = pmc("pmc_sq"), pmc("pmc_lds"), pmc("pmc_fetch"), pmc("pmc_write")
+# ---- HBM + Infinity-Cache bytes PER STEP: every dispatch of the pass summed, divided by the number of steps the pass ran (= the
+# number of stem launches: one per step).  FETCH_SIZE x 2 (gfx950 wide-load correction) + WRITE_SIZE, counters in KB.
+per_step = None
+ft, fc = pmc_totals("pmc_fetch", "FETCH_SIZE")
+wt, wc_ = pmc_totals("pmc_write", "WRITE_SIZE")
+stem = [k for k in fc if k.startswith("stem7x7")]
+if stem and all(k in wc_ for k in stem):
+    nsteps = sum(fc[k] for k in stem)
+    assert nsteps == sum(wc_[k] for k in stem), "the FETCH and WRITE passes ran different numbers of steps"
+    by_kernel = {k: (2.0 * ft[k] + wt.get(k, 0.0)) * 1024.0 / nsteps for k in ft}
+    conv = lambda k: k.startswith(("conv3x3", "conv_reduce", "wino", "tail_kernel", "fc_finish"))   # noqa: E731
+    per_step = {"steps_counted": int(nsteps), "all_kernels_bytes": int(sum(by_kernel.values())),
+                "conv_family_bytes": int(sum(v for k, v in by_kernel.items() if conv(k) and not k.startswith("wino_weight"))),
+                "launches_per_step": {k: round(fc[k] / nsteps, 3) for k in fc if not k.startswith("wino_weight")},
+                "bytes_per_step_by_kernel": {k: int(v) for k, v in by_kernel.items() if not k.startswith("wino_weight")},
+                "note": "sum over every dispatch of the FETCH_SIZE (x2) and WRITE_SIZE passes / steps of the pass; Infinity-Cache hits included"}
 dur = {short(r["Name"]): float(r["AverageNs"]) for r in ours}
 if sq:
     lines.append("\n## PMC (separate passes, averages per dispatch)\n")
@@ -82,6 +110,12 @@ if sq:
             100 * d.get("SQ_WAIT_INST_ANY", 0) / wc if wc else 0,
             "%.1f" % (2 * f / 1024) if f is not None else "-", "%.1f" % (w / 1024) if w is not None else "-", bc))
     with open(dst + "_pmc.json", "w") as f:
-        json.dump({"sq": sq, "lds": lds, "fetch": fe, "write": wr}, f, indent=1)
+        json.dump({"sq": sq, "lds": lds, "fetch": fe, "write": wr, "per_step": per_step}, f, indent=1)
+    if per_step:
+        lines.append("\n## HBM + Infinity-Cache bytes per step (every dispatch of the FETCH x2 / WRITE passes summed, / %d steps)\n" % per_step["steps_counted"])
+        lines.append("all kernels %.1f MB, conv family %.1f MB\n" % (per_step["all_kernels_bytes"] / 1e6, per_step["conv_family_bytes"] / 1e6))
+        lines.append("| kernel | launches / step | MB / step |\n|---|---|---|")
+        for k, v in sorted(per_step["bytes_per_step_by_kernel"].items(), key=lambda kv: -kv[1]):
+            lines.append("| %s | %s | %.1f |" % (k, per_step["launches_per_step"].get(k), v / 1e6))
 open(dst + "_summary.md", "w").write("# rocprofv3 summary %s\n\n" % os.path.basename(dst) + "\n".join(lines) + "\n")
 print("\n".join(lines))

@@ -238,3 +238,33 @@ def test_model_points_and_object_width(se3, tmp_path):
     from scipy.spatial.distance import pdist
     assert abs(w - pdist(ds).max() * 1000) < 1e-6
     assert U.crop_window(np.array([[48, 213], [381, 213], [48, 546], [381, 546]])) == (213, 48, 546, 381)
+
+
+def test_winograd_tile_codes_offset_rule_and_the_ctypes_mirror(se3):
+    """The constants the Python mirror repeats are the header's; se3tn_set_winograd / se3tn_set_offset_rule accept exactly the
+    documented codes (host-only context: no device work)."""
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "se3tracknet.h")).read()
+
+    def h(name, conv=int):
+        return conv(re.search(r"#define %s ([0-9.]+)" % name, hdr).group(1))
+    L = se3._lib
+    assert (h("SE3TN_WINOGRAD_TILE_AUTO"), h("SE3TN_WINOGRAD_TILE_6_4"), h("SE3TN_WINOGRAD_TILE6_MIN_BATCH")) == \
+        (L.WINOGRAD_TILE_AUTO, L.WINOGRAD_TILE_6_4, L.WINOGRAD_TILE6_MIN_BATCH)
+    assert h("SE3TN_WINOGRAD_HEADS_TILE6_MAX_ROT", float) == L.WINOGRAD_HEADS_TILE6_MAX_ROT
+    assert (h("SE3TN_OFFSET_RULE_NUMPY1"), h("SE3TN_OFFSET_RULE_NUMPY2")) == (L.OFFSET_RULE_NUMPY1, L.OFFSET_RULE_NUMPY2)
+    eng = se3.Engine(device=-1, max_batch=1)
+    lib = L.load()
+    assert eng.get_winograd() == (h("SE3TN_WINOGRAD_DEFAULT_MIN_BATCH"), L.WINOGRAD_TILE_AUTO)
+    for tile in (2, 4, 6, L.WINOGRAD_TILE_6_4, L.WINOGRAD_TILE_AUTO):
+        eng.set_winograd(9, tile)
+        assert eng.get_winograd() == (9, tile)
+    eng.set_winograd(3)                                  # tile 0 keeps the tile
+    assert eng.get_winograd() == (3, L.WINOGRAD_TILE_AUTO)
+    for bad in (1, 3, 5, 8, 46 + 1, 63):
+        assert lib.se3tn_set_winograd(eng._h, 6, bad) == -1
+    assert eng.get_offset_rule() == "numpy1"             # the reference's pinned NumPy generation is the default
+    eng.set_offset_rule("numpy2")
+    assert eng.get_offset_rule() == "numpy2" and lib.se3tn_get_offset_rule(eng._h) == L.OFFSET_RULE_NUMPY2
+    eng.set_offset_rule(L.OFFSET_RULE_NUMPY1)
+    assert eng.get_offset_rule() == "numpy1"
+    assert lib.se3tn_set_offset_rule(eng._h, 2) == -1 and lib.se3tn_get_offset_rule(None) == -1
