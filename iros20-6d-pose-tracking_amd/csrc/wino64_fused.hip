@@ -25,6 +25,10 @@
 // fragment layout as conv3x3_mfma.hip / wino_mfma.hip.
 #include "mfma_common.h"
 
+#ifndef W64_KNOCKOUT
+#define W64_KNOCKOUT 0   // timing knock-outs (wrong results): bit 0 = no window reads from the LDS patch
+#endif
+
 namespace se3tn {
 
 namespace {
@@ -255,7 +259,8 @@ __global__ __launch_bounds__(512) void wino64_fused_kernel(const Wino64Args a) {
                                W64Tab::bt_n1(i_) != W64Tab::bt_n0(j_), W64Tab::bt_n1(i_) != W64Tab::bt_n1(j_)}; \
       _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                                                          \
         _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                                                      \
-          *reinterpret_cast<float4*>(d_[t_][w_]) = *reinterpret_cast<const float4*>(patch + tpix[t_] + oo_[w_]); \
+          if (W64_KNOCKOUT & 1) *reinterpret_cast<float4*>(d_[t_][w_]) = make_float4(1.f, 2.f, 3.f, 4.f); /* timing only */ \
+          else *reinterpret_cast<float4*>(d_[t_][w_]) = *reinterpret_cast<const float4*>(patch + tpix[t_] + oo_[w_]); \
         }                                                                                                      \
       constexpr int pi_ = fp_ >> 2, pj_ = fp_ & 3;   /* fold: products of the previous step (zeros before the first) */ \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
