@@ -66,6 +66,7 @@ struct se3tn_ctx {
   float* fcpart = nullptr;                      // [mb,2,8,3] partial FC dot products of the fused Winograd tail
   bool keep_intermediates = false;              // se3tn_keep_intermediates: fused blocks also store ab_t / head_t / head
   int auto_tile_override[2] = {0, 0};           // SE3TN_WINOGRAD_AUTO_TILE_AB2 / _HEADS = 4 | 6: what AUTO picks per block (rounding studies)
+  int gemmp = -1;                               // SE3TN_WINO_GEMMP = 0 | 1: never | always the persistent 128 x 256 Winograd GEMM (default: by tile count)
   bool wino_fuse = true;                        // whole residual blocks as one fused launch sequence (SE3TN_WINOGRAD_FUSE=0: conv by conv)
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
   size_t part_bytes = 0;
@@ -308,6 +309,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
   c->SL = split_layout();
   if (const char* e = std::getenv("SE3TN_WINOGRAD_AUTO_TILE_AB2")) c->auto_tile_override[0] = (std::atoi(e) == 4 || std::atoi(e) == 6) ? std::atoi(e) : 0;
   if (const char* e = std::getenv("SE3TN_WINOGRAD_AUTO_TILE_HEADS")) c->auto_tile_override[1] = (std::atoi(e) == 4 || std::atoi(e) == 6) ? std::atoi(e) : 0;
+  if (const char* e = std::getenv("SE3TN_WINO_GEMMP")) c->gemmp = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("SE3TN_WINOGRAD_FUSE")) c->wino_fuse = std::atoi(e) != 0;      // developer A/B switch (and the tests'
                                                                                                   // bit-equality check of the two forms)
   if (const char* e = std::getenv("SE3TN_TRUNK_WINOGRAD")) c->wino64_min_batch = std::atoi(e);   // developer A/B switch
@@ -747,7 +749,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
       w.C = s.cin; w.Cout = s.cout; w.groups = s.groups;
       w.in_gs = in_gs; w.res_gs = res_gs; w.out_gs = out_gs; w.bias_gs = s.cout;
       w.u_gs = (long long)w.nf * s.cin * s.cout;
-      w.num_cus = c->num_cus;
+      w.num_cus = c->num_cus; w.gemmp = c->gemmp;
       hipError_t e = launch_wino_conv(w, epi, st);
       if (e != hipSuccess) return hipfail(e, name);
       return prof_mark(c, st, c->prof ? algo_name(name, wtile) : name, true);
@@ -812,7 +814,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
     w.C = s.cin; w.Cout = s.cout; w.groups = s.groups;
     w.in_gs = gs; w.res_gs = gs; w.out_gs = gs; w.bias_gs = s.cout;
     w.u_gs = (long long)w.nf * s.cin * s.cout;
-    w.num_cus = c->num_cus;
+    w.num_cus = c->num_cus; w.gemmp = c->gemmp;
     const float *U2 = Uset[wino_slot(id2)], *usc2 = nullptr;
     float* keep2 = (tl && c->keep_intermediates) ? io : nullptr;
     if (fast) {   // f16x3: split-row activations / V / U, float32 M

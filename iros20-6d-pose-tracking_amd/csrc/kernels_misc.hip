@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ hea
   constexpr int PP = (S4 + 2) * (S4 + 2);
   const float* src = head + (size_t)n * PP * 1024 + t * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  // History: for this loop hipcc once kept the (x, y) sums swapped in their register pair and added
+  // History (profiles/EXPERIMENTS.md items 13): for this loop hipcc once kept the (x, y) sums swapped in their register pair and added
   // with `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]`; on gfx950 that form returns wrong lanes 48-63 while another kernel's waves
   // issue v_mfma_f32_32x32x16_f16 on the same CU (two f16x3 contexts in flight: wrong sums in 40-85 % of the launches).  The device
   // code is therefore compiled without packed-float32 instructions (Makefile), and scripts/isa_lint.py checks the library for the form.

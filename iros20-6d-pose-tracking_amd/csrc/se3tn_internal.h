@@ -173,6 +173,7 @@ struct WinoArgs {
   int in_gs, res_gs, out_gs, bias_gs;
   long long u_gs;     // floats per group of U
   int num_cus;        // compute units of the device (0: 256); sizes the persistent GEMM grid
+  int gemmp;          // persistent 128 x 256 GEMM: -1 = when its tiles fill every CU twice, 0 = never, 1 = whenever the shape allows
   // f16x3 mode of the fused F(4x4) blocks (split != 0): in / res / out are split-row tensors, V is written as split rows, U points
   // at the split planes and uscale[g][f][Cout] holds their exact power-of-two scales (undone in the GEMM epilogue, M is float32)
   int split;

@@ -2,7 +2,7 @@
 // Se3TrackNet, se3_tracknet.py:59-64 via network_modules.py:86-120) on the 44 x 44 maps, for large batches.
 //
 // Why a different kernel.  The direct 64-channel kernels (conv3x3_slab_kernel<64,...>) sit at 0.70 of the f32 MFMA peak and cannot
-// move: K = 576 per tile and 968 / 484 tiles on 256 workgroups = 3.78 / 1.89 rounds.  The plain Winograd route
+// move: K = 576 per tile and 968 / 484 tiles on 256 workgroups = 3.78 / 1.89 rounds (profiles/EXPERIMENTS.md).  The plain Winograd route
 // (transform pass -> batched GEMM -> transform pass, wino_mfma.hip) does not pay at 64 channels: the V / M planes are 4x the activation
 // and the 16 GEMMs have K = 64 -- the passes alone cost what the direct kernel costs.  This kernel keeps EVERYTHING on the chip:
 //
@@ -17,7 +17,7 @@
 //       Y[y][x] += A^T[y][i] A^T[x][j] M_f   in registers (A^T entries are 0 / +-1): the 16 M_f never exist at the same time
 //   the step is software-pipelined inside every wave (MFMAs of step s | fold of step s - 1 | operand tile of step s + 1) and the 16
 //   frequencies are unrolled, so that every B^T / A^T entry is a compile-time 0 / +-1: vector work is NOT hidden behind MFMAs on
-//   gfx950 (profiles/r03_probe_mfma_valu.txt), the instruction count of a step is what the kernel's time follows
+//   gfx950 (profiles/r03_probe_mfma_valu.txt), the instruction count of a step is what the kernel's time follows (profiles/EXPERIMENTS.md items 23-24)
 //   at the end Y is staged through LDS: + bias (+ residual), ReLU, pixel-major float4 stores of the 2 x 2 outputs per tile.
 //
 // MFMA work: 16 x 2 x (128 x 64 x 32) MACs per workgroup = 2.13x less than direct (incl. the 7 unused rows).  Float32 throughout; rounding as
@@ -60,7 +60,7 @@ __device__ __forceinline__ void at_col(int i, float& a0, float& a1) {
 // Vector adds with compile-time signs, as inline asm: (1) asm volatile stays where it is written -- plain C++ adds the compiler sinks
 // below the step's barrier, all of them; (2) the signs ride on the operands' neg modifiers, no extra instruction.
 // (Packed v_pk_add_f32 / v_pk_fma_f32 were measured and dropped: on gfx950 a packed float32 instruction costs exactly two scalar ones,
-// profiles/r03_probe_mfma_valu.txt, and the library stays free of packed-f32 code)
+// profiles/r03_probe_mfma_valu.txt, and the library stays free of packed-f32 code, profiles/EXPERIMENTS.md items 13.)
 template <bool NA, bool NB>
 __device__ __forceinline__ float add_pm(const float a, const float b) {   // (+|-) a (+|-) b
   float r;

@@ -26,7 +26,6 @@
 // (tests/test_gpu_parity.py::test_winograd_*).
 #include "mfma_common.h"
 #include "pose_device.h"
-#include <cstdlib>
 
 #ifndef WINO4_VEC
 #define WINO4_VEC 2  // channels per thread of the F(4x4) transform kernels (2: 8-byte, 4: 16-byte accesses; measured equal)
@@ -1076,12 +1075,13 @@ static hipError_t launch_gemm_auto(const WinoArgs& a, hipStream_t st) {
   const long long q96 = ((((a.T + 95) / 96) * per_b + 255) / 256) * 12;
   if (a.split) return q96 < q128 ? launch_gemm<CIN, 1, 4, 3, 1, MM_F16X3>(a, st) : launch_gemm<CIN, 2, 2, 2, 2, MM_F16X3>(a, st);
   // persistent 128 x 256 tiles, one 8-wave workgroup per CU: when they fill every CU at least twice (F(6x6) at batch 64: exactly 2.0)
-  // and the plane count lets the XCD-local tile order cover them (groups nf % 8 == 0: 36 F(4x4) planes do not)
-  if (SE3TN_WINO_GEMMP && a.Cout % 256 == 0 && (a.groups * a.nf) % 8 == 0) {
+  // and the plane count lets the XCD-local tile order cover them (groups nf % 8 == 0: 36 F(4x4) planes do not).
+  // a.gemmp: -1 = that rule, 0 = never, 1 = whenever the shape allows (SE3TN_WINO_GEMMP at se3tn_create: A/B runs and the tests'
+  // bit-equality check of the two kernels on ragged shapes)
+  if (SE3TN_WINO_GEMMP && a.gemmp != 0 && a.Cout % 256 == 0 && (a.groups * a.nf) % 8 == 0) {
     const int cus = a.num_cus > 0 ? a.num_cus : 256;
     const int tiles = (a.Cout / 256) * ((a.T + 127) / 128) * a.groups * a.nf;
-    static const int force = std::getenv("SE3TN_WINO_GEMMP") ? std::atoi(std::getenv("SE3TN_WINO_GEMMP")) : -1;   // developer A/B switch
-    if (force != 0 && (force == 1 || tiles >= 2 * cus)) return launch_gemmp<CIN>(a, tiles, tiles < cus ? tiles : (cus / 8) * 8, st);
+    if (a.gemmp == 1 || tiles >= 2 * cus) return launch_gemmp<CIN>(a, tiles, tiles < cus ? tiles : (cus / 8) * 8, st);
   }
   if (SE3TN_WINO_GEMM8 && q96 < q128) return launch_gemm8<CIN>(a, st);
   return q96 < q128 ? launch_gemm<CIN, 1, 4, 3, 1>(a, st) : launch_gemm<CIN, 2, 2, 2, 2>(a, st);

@@ -1,4 +1,4 @@
-// Probe for DESIGN.md section 7 item 13: a reader that sums 169 rows of a CONSTANT buffer (nobody writes it) with
+// Probe for profiles/EXPERIMENTS.md items 13: a reader that sums 169 rows of a CONSTANT buffer (nobody writes it) with
 // three wait disciplines, launched on its own stream while another stream runs the library's kernels.
 //   pool_counted : `for p: s += row[p]`          -> 13 loads in flight, counted s_waitcnt vmcnt(12..0), each followed
 //                                                    at once by the add that consumes the row (the old tail_kernel loop)

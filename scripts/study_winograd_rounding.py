@@ -2,7 +2,7 @@
 """CPU study (no GPU): what would F(6x6,3x3) cost in float32 rounding?
 
 The Winograd GEMMs of the 256 / 512-channel blocks lose 16 % to workgroup quantisation at batch 64 (3.375 tiles per slot,
-DESIGN.md section 7 item 16); F(6x6,3x3) would give exactly 2.0 tiles per slot AND 21 % fewer multiplies and plane bytes.  Its
+profiles/EXPERIMENTS.md items 16); F(6x6,3x3) would give exactly 2.0 tiles per slot AND 21 % fewer multiplies and plane bytes.  Its
 transforms amplify float32 rounding more than F(4x4)'s.  This script measures by how much, end to end, with the oracle network:
 the four 256 / 512-channel stride-1 convs are replaced by a float32 emulation of the device algorithm (U = G g G^T in float64 rounded
 once, B^T d B / the per-frequency products / A^T M A in float32) for m = 2, 4, 6 and compared with a float64 forward of the same

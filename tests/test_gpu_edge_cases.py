@@ -328,7 +328,7 @@ def test_pipelined_engine_lanes_share_weights_and_match_single_engine(se3):
 def test_two_contexts_queued_on_two_streams_are_bit_identical_to_one(se3, precision, n):
     """Throughput mode under load: two contexts, two streams, the infers of a whole round queued back to back
     with no host synchronisation in between; every launch must reproduce the single-context logits bit for
-    bit.  Regression test for DESIGN.md section 7 item 13: with two f16x3 contexts in flight the average-pool of
+    bit.  Regression test for profiles/EXPERIMENTS.md items 13: with two f16x3 contexts in flight the average-pool of
     tail_kernel was wrong in 40-85 % of the launches, because hipcc had emitted `v_pk_add_f32 ... op_sel:[0,1]
     op_sel_hi:[1,0]`, a form that returns wrong lanes 48-63 on gfx950 while another kernel issues
     v_mfma_f32_32x32x16_f16 on the same CU (scripts/probes/pk_opsel.hip; tests/test_isa_lint.py guards the build)."""

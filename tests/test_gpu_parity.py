@@ -492,6 +492,33 @@ def test_fused_winograd_blocks_equal_the_conv_by_conv_form(se3, tile):
     _close("fused logits vs oracle", res["1"][1][:2], torch.cat([ref["trans_logit"], ref["rot_logit"]], 1), 0, NET_TOL)
 
 
+@pytest.mark.parametrize("n", [20, 64])
+def test_persistent_winograd_gemm_equals_the_tiled_one_bitwise(se3, n):
+    """`wino_gemmp_kernel` (128 x 256 tiles, 8 waves, one persistent workgroup per CU, XCD-local tile order; the default from two
+    tiles per CU = batch 64) against `wino_gemm_kernel` (128 | 96 x 128, 4 waves): same fragment layout and k order, so every
+    per-frequency product -- and with them the logits and `feature` -- must be BIT-identical.  SE3TN_WINO_GEMMP = 1 | 0 forces
+    either (read at se3tn_create).  n = 20: ragged row tiles (320 / 80 Winograd tiles: 3 / 1 tiles of 128 rows), fewer tiles than
+    CUs x 2 (the persistent loop runs 1-2 tiles per workgroup); n = 64: exactly 2 tiles per CU."""
+    sd = O.make_state_dict(0)
+    A, B = Fx.net_inputs(77, n)
+    Ac, Bc = A.cuda(), B.cuda()
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["SE3TN_WINO_GEMMP"] = mode
+        try:
+            m = se3.Se3TrackNet(176, max_batch=n)
+            m.load_state_dict(sd)
+            m.cuda(0)
+        finally:
+            del os.environ["SE3TN_WINO_GEMMP"]
+        m.engine.set_winograd(1, 6)
+        out = m(Ac, Bc)
+        res[mode] = (out["feature"].cpu().clone(), m.engine.logits(n).cpu().clone())
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+    ref = O.forward(sd, A[:2], B[:2])
+    _close("logits vs oracle", res["1"][1][:2], torch.cat([ref["trans_logit"], ref["rot_logit"]], 1), 0, NET_TOL)
+
+
 def test_batch_permutation_equivariance_bitwise(se3, model0):
     """Size-independent property at BASELINE's batch: permuting the 64 pairs permutes the outputs BITWISE
     (no pair's result depends on its neighbours or on where its pixels / Winograd tiles fall in a

@@ -1,5 +1,5 @@
 """The built library must not contain the packed-float32 form that gfx950 mis-executes beside 16-bit MFMAs of another
-kernel (scripts/isa_lint.py disassembles every code object in the .so)."""
+kernel (profiles/EXPERIMENTS.md items 13; scripts/isa_lint.py disassembles every code object in the .so)."""
 import importlib.util
 import os
 

@@ -47,5 +47,5 @@ def test_end_to_end_rounding_of_the_tiles():
         out = st.forward_with(sd, A, B, st.WinoConv(key) if key else None)
         err[key] = float((torch.cat([out["trans_logit"], out["rot_logit"]], 1).double() - want).abs().max())
     print("max |d logit| vs float64: direct f32 %.2e, F(4x4) %.2e, F(6x6) %.2e" % (err[None], err[4], err[6]))
-    assert err[None] < 2e-6 and err[4] < 2e-6 and err[6] < 4e-6      # 0.5 / 0.6 / 1.4e-6
+    assert err[None] < 2e-6 and err[4] < 2e-6 and err[6] < 4e-6      # profiles/EXPERIMENTS.md items 25: 0.5 / 0.6 / 1.4e-6
     assert err[6] < 6 * max(err[4], 3e-7)                             # not the 10-20 x a single layer's figures suggest
