@@ -66,6 +66,7 @@ struct se3tn_ctx {
   float* fcpart = nullptr;                      // [mb,2,8,3] partial FC dot products of the fused Winograd tail
   bool keep_intermediates = false;              // se3tn_keep_intermediates: fused blocks also store ab_t / head_t / head
   int auto_tile_override[2] = {0, 0};           // SE3TN_WINOGRAD_AUTO_TILE_AB2 / _HEADS = 4 | 6: what AUTO picks per block (rounding studies)
+  int trunk_kernel = 1;                         // SE3TN_TRUNK_KERNEL = 2: the register-V trunk experiment (only in -DSE3TN_TRUNK_REGV=1 builds)
   int gemmp = -1;                               // SE3TN_WINO_GEMMP = 0 | 1: never | always the persistent 128 x 256 Winograd GEMM (default: by tile count)
   bool wino_fuse = true;                        // whole residual blocks as one fused launch sequence (SE3TN_WINOGRAD_FUSE=0: conv by conv)
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
@@ -309,6 +310,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
   c->SL = split_layout();
   if (const char* e = std::getenv("SE3TN_WINOGRAD_AUTO_TILE_AB2")) c->auto_tile_override[0] = (std::atoi(e) == 4 || std::atoi(e) == 6) ? std::atoi(e) : 0;
   if (const char* e = std::getenv("SE3TN_WINOGRAD_AUTO_TILE_HEADS")) c->auto_tile_override[1] = (std::atoi(e) == 4 || std::atoi(e) == 6) ? std::atoi(e) : 0;
+  if (const char* e = std::getenv("SE3TN_TRUNK_KERNEL")) c->trunk_kernel = std::atoi(e) == 2 ? 2 : 1;
   if (const char* e = std::getenv("SE3TN_WINO_GEMMP")) c->gemmp = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("SE3TN_WINOGRAD_FUSE")) c->wino_fuse = std::atoi(e) != 0;      // developer A/B switch (and the tests'
                                                                                                   // bit-equality check of the two forms)
@@ -757,7 +759,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
     if (id <= L64_4 && !fast && wino64_pays(c, n, s.groups) && c->wino64_blob == c->blob && stride == 1 && hin == S2 && epi != 2) {
       const int slot64 = (int)id - (int)L64_1;
       hipError_t e = launch_wino64(in, in_ld, in_gs, c->wino64_u[slot64], (long long)16 * s.cin * s.cout, W + L.conv_b[id], s.cout, res,
-                                   res_ld, res_gs, out, out_ld, out_gs, n, s.groups, epi, st);
+                                   res_ld, res_gs, out, out_ld, out_gs, n, s.groups, epi, c->trunk_kernel, st);
       if (e != hipSuccess) return hipfail(e, name);
       static const char* const fused_names[4] = {"conv64 A2.conv1|B2.conv1 [fused F(2x2)]", "conv64 A2.conv2|B2.conv2 [fused F(2x2)]",
                                                  "conv64 B3.conv1 [fused F(2x2)]", "conv64 B3.conv2 [fused F(2x2)]"};

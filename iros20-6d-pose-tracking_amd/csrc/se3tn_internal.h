@@ -245,7 +245,7 @@ hipError_t launch_wino_conv(const WinoArgs& a, int epi, hipStream_t st);
 // fused Winograd F(2x2,3x3) of a 64 -> 64 channel convolution on the 44 x 44 maps (wino64_fused.hip); U: F(2x2) planes of launch_wino_weights
 hipError_t launch_wino64(const float* in, int in_ld, int in_gs, const float* U, long long u_gs, const float* bias, int bias_gs,
                          const float* res, int res_ld, int res_gs, float* out, int out_ld, int out_gs, int n, int groups, int epi,
-                         hipStream_t st);
+                         int variant, hipStream_t st);
 // a whole residual block on the Winograd F(4x4) path with the fused mid / tail transforms (wino_mfma.hip);
 // mark_after_mid: optional profiling hook called between conv1 and conv2 (returns non-zero on error)
 hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* uscale2, const float* bias2, float* out2, int keep_mid,

@@ -26,7 +26,8 @@
 #include "mfma_common.h"
 
 #ifndef W64_KNOCKOUT
-#define W64_KNOCKOUT 0   // timing knock-outs (wrong results): bit 0 = no window reads from the LDS patch
+#define W64_KNOCKOUT 0   // timing knock-outs (wrong results): bit 0 = no window reads from the LDS patch;
+                         // wino64_regv_kernel: bit 1 = no U loads after the first, bit 2 = no window reads
 #endif
 
 namespace se3tn {
@@ -353,28 +354,250 @@ __global__ __launch_bounds__(512) void wino64_fused_kernel(const Wino64Args a) {
   }
 }
 
+#ifndef SE3TN_TRUNK_REGV
+#define SE3TN_TRUNK_REGV 0
+#endif
+#if SE3TN_TRUNK_REGV
+// =================================================================================================================================
+// wino64_regv_kernel -- the same fused F(2x2,3x3) convolution WITHOUT a barrier in its main loop (round-4 EXPERIMENT, compiled only with
+// -DSE3TN_TRUNK_REGV=1 and selected by SE3TN_TRUNK_KERNEL=2: parity tests green, SLOWER than wino64_fused_kernel -- 137 / 146 / 71 / 76 us
+// against 110 / 116 / 56 / 60; knock-outs: without its U loads 101 / 108 / 53 / 56, without window reads as well 96 / 104 / 51 / 55 = this
+// algorithm's floor (MFMA + vector adds + prologue / epilogue), which the shipped kernel is within 12-14 % of.  profiles/EXPERIMENTS.md item 32).
+// What the first form pays per step besides its MFMAs and its vector adds is the workgroup-wide rendezvous: V_f goes through LDS (every
+// thread builds two pieces of a tile all eight waves read), U_f arrives by LDS-DMA, so all waves meet at a barrier 32 times, wait for each
+// other's skew, then all issue their fragment reads at once (measured: ~20 % of a step is neither matrix nor vector time).  Here:
+//   * a wave owns 16 tiles x all 64 couts and runs v_mfma_f32_16x16x4_f32 (4 cout blocks = 4 independent accumulators): the B operand of a
+//     lane is V of ITS tile for 8 channels -- exactly what that lane's two float4 window transforms produce.  V never leaves registers;
+//   * the A operand (U_f: 64 couts x 32 channels = 8 KB per step) is read straight from global memory by every wave (8 x float4 per lane
+//     per step, one step ahead): the 8 KB tile is shared by the eight waves through the L1 and by all workgroups through L2 (256 KB per
+//     chunk for the whole launch);
+//   * both 32-channel chunk patches are resident in LDS (2 x 73.7 KB), XOR-swizzled by LDS column (slot = channel block ^ (column & 7)) so
+//     that the 16 lanes of a ds_read_b128 group -- 16 neighbouring tiles, two channel blocks -- cover all 64 banks;
+//   * so after the prologue the only workgroup barrier is the one before chunk 1's patch is first read; the waves drift apart and the two
+//     waves of a SIMD fill each other's vector phases with MFMAs by themselves.
+// Arithmetic: the same products and sums per output as wino64_fused_kernel in the same frequency order; the k order inside a 32-channel
+// chunk differs (4 (jq + 4 h) + c instead of ascending), so results agree to float32 rounding, not bitwise.
+// =================================================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI>
+__global__ __launch_bounds__(512) void wino64_regv_kernel(const Wino64Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [chunk 2][24][24][8 slots][4]; the epilogue's staging afterwards
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, jq = lane >> 4;   // tile within the wave's 16 | k quarter = channel blocks jq, jq + 4
+
+  const int g = blockIdx.x % a.groups, rest = blockIdx.x / a.groups;
+  const int quad = rest & 3, img = rest >> 2;
+  const int y0 = (quad >> 1) * 2 * W64_TILES, x0 = (quad & 1) * 2 * W64_TILES;
+  constexpr int HP = 46;
+  const float* __restrict__ in = a.in + (size_t)g * a.in_gs + ((size_t)(img * HP + y0) * HP + x0) * a.in_ld;
+  const float* __restrict__ Ug = a.U + (size_t)g * a.u_gs;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+  // patch piece id = tid + 512 j (j < 9): LDS pixel id >> 3 (row-major 24 x 24, LDS column lc holds patch column lc < 12 ? 2 lc : 2 lc - 23),
+  // LDS slot id & 7 holds channel block (id & 7) ^ (lc & 7)
+#define W64R_ISSUE_PATCH(CH)                                                                                    \
+  {                                                                                                            \
+    const float* pb_ = in + (CH) * 32;                                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < 9; ++j_) {                                                          \
+      const int id_ = tid + 512 * j_, px_ = id_ >> 3, py_ = px_ / W64_PATCH, lc_ = px_ - py_ * W64_PATCH;       \
+      const int xs_ = lc_ < 12 ? 2 * lc_ : 2 * lc_ - 23;                                                        \
+      glds16<0>(pb_, (unsigned)(((py_ * HP + xs_) * a.in_ld + (((id_ & 7) ^ (lc_ & 7)) << 2)) * 4),             \
+                lds0 + (unsigned)(((CH) * W64_PATCH_FLOATS) * 4 + (wid * 64 + 512 * j_) * 16));                 \
+    }                                                                                                          \
+  }
+
+  // this lane's tile (the 7 rows past tile 120 repeat tile 120: computed, never stored) and its window bases: float offsets of window
+  // column s (0..3), channel-block half h, row 0; a window row adds r x 768 floats (24 pixels x 8 slots x 4)
+  const int tt = wid * 16 + r16;
+  const int ttr = tt < W64_TILES * W64_TILES ? tt : W64_TILES * W64_TILES - 1;
+  const int tty = ttr / W64_TILES, ttx = ttr - tty * W64_TILES;
+  int pb[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int lc = (s & 1) ? 12 + ttx + (s >> 1) : ttx + (s >> 1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) pb[s][h] = ((2 * tty * W64_PATCH + lc) * 8 + ((jq + 4 * h) ^ (lc & 7))) * 4;
+  }
+  const float* __restrict__ ul = Ug + r16 * 32 + jq * 4;   // + ((chunk 16 + f) 64 + 16 b) 32 + 16 h
+#define W64R_LOAD_U(DST, CH, F)                                                                                 \
+  _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)             \
+      DST[b_][h_] = *reinterpret_cast<const float4*>(ul + ((CH) * 16 + (F)) * W64_U_FLOATS + b_ * 512 + h_ * 16);
+
+  float Y[16][4];   // Y[e][o]: accumulator element e = 4 b + reg (cout 16 b + 4 jq + reg) of output pixel o = 2 y + x of the tile
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) Y[e][o] = 0.f;
+
+  float4 Ua[4][2], Ub[4][2];
+  float Va[2][4], Vb[2][4];
+  f32x4 accA[4], accB[4];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < 4; ++b) accB[b] = zero4;
+
+  W64R_ISSUE_PATCH(0)
+  W64R_LOAD_U(Ua, 0, 0)
+  wait_dma_and_barrier();
+  W64R_ISSUE_PATCH(1)   // lands under the first steps; every wave waits for its own pieces, the barrier before step 15 for the others'
+  {   // V of step 0: frequency (0, 0) = (d0 - d2) x (d0 - d2)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4 d00 = *reinterpret_cast<const float4*>(smem + pb[0][h]), d02 = *reinterpret_cast<const float4*>(smem + pb[2][h]);
+      const float4 d20 = *reinterpret_cast<const float4*>(smem + pb[0][h] + 2 * 768), d22 = *reinterpret_cast<const float4*>(smem + pb[2][h] + 2 * 768);
+      Va[h][0] = (d00.x - d02.x) - (d20.x - d22.x); Va[h][1] = (d00.y - d02.y) - (d20.y - d22.y);
+      Va[h][2] = (d00.z - d02.z) - (d20.z - d22.z); Va[h][3] = (d00.w - d02.w) - (d20.w - d22.w);
+    }
+  }
+
+  // One step, frequency compile-time: [U of the next step: 8 global float4] [window of the next step: 8 ds_read_b128]
+  // 32 x { MFMA ; fold of the previous step's products (first 16) | transform of the next step's V (next 8) }
+#define W64R_STEP(F, UC, UN, VC, VN, ACC, PREV)                                                                 \
+  {                                                                                                            \
+    constexpr int f_ = (F), fn_ = (f_ + 1) & 15, fp_ = (f_ + 15) & 15;                                          \
+    const bool last_ = ch == 1 && f_ == 15;                                                                    \
+    const int chn_ = f_ == 15 ? 1 : ch;                                                                        \
+    if (f_ == 15 && ch == 0) wait_dma_and_barrier();   /* chunk 1's patch: every wave's pieces have landed */     \
+    if (!last_ && !(W64_KNOCKOUT & 2)) W64R_LOAD_U(UN, chn_, fn_)                                               \
+    if (W64_KNOCKOUT & 2) { _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) { UN[b_][0] = UC[b_][1]; UN[b_][1] = UC[b_][0]; } } /* timing only */ \
+    constexpr int i_ = fn_ >> 2, j_ = fn_ & 3;                                                                 \
+    constexpr int ra_ = W64Tab::bt_r0(i_) * 768, rb_ = W64Tab::bt_r1(i_) * 768;                                \
+    constexpr int sa_ = W64Tab::bt_r0(j_), sb_ = W64Tab::bt_r1(j_);                                            \
+    constexpr bool nn_[4] = {W64Tab::bt_n0(i_) != W64Tab::bt_n0(j_), W64Tab::bt_n0(i_) != W64Tab::bt_n1(j_),    \
+                             W64Tab::bt_n1(i_) != W64Tab::bt_n0(j_), W64Tab::bt_n1(i_) != W64Tab::bt_n1(j_)};   \
+    const float* pn_ = smem + chn_ * W64_PATCH_FLOATS;                                                          \
+    float d_[2][4][4];                                                                                         \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                          \
+      if (W64_KNOCKOUT & 4) { _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) *reinterpret_cast<float4*>(d_[h_][w_]) = make_float4(1.f, 2.f, 3.f, 4.f); continue; } \
+      *reinterpret_cast<float4*>(d_[h_][0]) = *reinterpret_cast<const float4*>(pn_ + pb[sa_][h_] + ra_);        \
+      *reinterpret_cast<float4*>(d_[h_][1]) = *reinterpret_cast<const float4*>(pn_ + pb[sb_][h_] + ra_);        \
+      *reinterpret_cast<float4*>(d_[h_][2]) = *reinterpret_cast<const float4*>(pn_ + pb[sa_][h_] + rb_);        \
+      *reinterpret_cast<float4*>(d_[h_][3]) = *reinterpret_cast<const float4*>(pn_ + pb[sb_][h_] + rb_);        \
+    }                                                                                                          \
+    constexpr int pi_ = fp_ >> 2, pj_ = fp_ & 3;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    _Pragma("unroll") for (int m_ = 0; m_ < 32; ++m_) {                                                         \
+      const int q_ = m_ >> 2, b_ = m_ & 3, h_ = q_ >> 2, k_ = q_ & 3;                                          \
+      const float ua_ = k_ == 0 ? UC[b_][h_].x : k_ == 1 ? UC[b_][h_].y : k_ == 2 ? UC[b_][h_].z : UC[b_][h_].w; \
+      ACC[b_] = q_ == 0 ? __builtin_amdgcn_mfma_f32_16x16x4f32(ua_, VC[h_][k_], zero4, 0, 0, 0)                 \
+                        : __builtin_amdgcn_mfma_f32_16x16x4f32(ua_, VC[h_][k_], ACC[b_], 0, 0, 0);              \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      if (m_ < 16) {   /* fold element m_ of the previous step's products */                                     \
+        const float m__ = PREV[m_ >> 2][m_ & 3];                                                                \
+        acc_pm<W64Tab::at(0, pi_) * W64Tab::at(0, pj_)>(Y[m_][0], m__);                                        \
+        acc_pm<W64Tab::at(0, pi_) * W64Tab::at(1, pj_)>(Y[m_][1], m__);                                        \
+        acc_pm<W64Tab::at(1, pi_) * W64Tab::at(0, pj_)>(Y[m_][2], m__);                                        \
+        acc_pm<W64Tab::at(1, pi_) * W64Tab::at(1, pj_)>(Y[m_][3], m__);                                        \
+      } else if (m_ < 24) {   /* the next step's V: 8 values (2 channel blocks x 4), its window reads have landed */ \
+        const int t_ = (m_ - 16) >> 2, x_ = (m_ - 16) & 3;                                                     \
+        VN[t_][x_] = add_pm<false, false>(add_pm<nn_[0], nn_[1]>(d_[t_][0][x_], d_[t_][1][x_]),                \
+                                          add_pm<nn_[2], nn_[3]>(d_[t_][2][x_], d_[t_][3][x_]));               \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+  }
+  for (int ch = 0; ch < 2; ++ch) {
+    W64R_STEP(0, Ua, Ub, Va, Vb, accA, accB) W64R_STEP(1, Ub, Ua, Vb, Va, accB, accA)
+    W64R_STEP(2, Ua, Ub, Va, Vb, accA, accB) W64R_STEP(3, Ub, Ua, Vb, Va, accB, accA)
+    W64R_STEP(4, Ua, Ub, Va, Vb, accA, accB) W64R_STEP(5, Ub, Ua, Vb, Va, accB, accA)
+    W64R_STEP(6, Ua, Ub, Va, Vb, accA, accB) W64R_STEP(7, Ub, Ua, Vb, Va, accB, accA)
+    W64R_STEP(8, Ua, Ub, Va, Vb, accA, accB) W64R_STEP(9, Ub, Ua, Vb, Va, accB, accA)
+    W64R_STEP(10, Ua, Ub, Va, Vb, accA, accB) W64R_STEP(11, Ub, Ua, Vb, Va, accB, accA)
+    W64R_STEP(12, Ua, Ub, Va, Vb, accA, accB) W64R_STEP(13, Ub, Ua, Vb, Va, accB, accA)
+    W64R_STEP(14, Ua, Ub, Va, Vb, accA, accB) W64R_STEP(15, Ub, Ua, Vb, Va, accB, accA)
+  }
+  {   // fold of step 31 (frequency 15 = (3, 3)): A^T column 3 = (0, -1) x (0, -1): only Y[.][3] += m
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float m = accB[e >> 2][e & 3];
+      acc_pm<W64Tab::at(0, 3) * W64Tab::at(0, 3)>(Y[e][0], m);
+      acc_pm<W64Tab::at(0, 3) * W64Tab::at(1, 3)>(Y[e][1], m);
+      acc_pm<W64Tab::at(1, 3) * W64Tab::at(0, 3)>(Y[e][2], m);
+      acc_pm<W64Tab::at(1, 3) * W64Tab::at(1, 3)>(Y[e][3], m);
+    }
+  }
+#undef W64R_STEP
+#undef W64R_LOAD_U
+#undef W64R_ISSUE_PATCH
+
+  // ---- epilogue: as wino64_fused_kernel (Y through LDS, pixel-major float4 stores); a lane holds tile tt x couts 16 b + 4 jq + 0..3
+  constexpr int YS = 4 * 64 + 4;
+  __syncthreads();   // every wave is done with the patches
+  if (tt < W64_TILES * W64_TILES) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        *reinterpret_cast<float4*>(smem + tt * YS + o * 64 + b * 16 + jq * 4) =
+            make_float4(Y[4 * b + 0][o], Y[4 * b + 1][o], Y[4 * b + 2][o], Y[4 * b + 3][o]);
+  }
+  __syncthreads();
+  const float* __restrict__ bias = a.bias + (size_t)g * a.bias_gs;
+  const float* __restrict__ res = (EPI == 1) ? a.res + (size_t)g * a.res_gs : nullptr;
+  float* __restrict__ out = a.out + (size_t)g * a.out_gs;
+  const int c4 = (tid & 15) * 4;
+  const float4 bq = *reinterpret_cast<const float4*>(bias + c4);
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int p = (k * 512 + tid) >> 4;
+    const int t = p >> 2, o = p & 3;
+    if (t < W64_TILES * W64_TILES) {
+      const int ty = t / W64_TILES, tx = t - ty * W64_TILES;
+      const int oy = y0 + 2 * ty + (o >> 1) + 1, ox = x0 + 2 * tx + (o & 1) + 1;
+      const size_t pix = (size_t)(img * HP + oy) * HP + ox;
+      float4 v = *reinterpret_cast<const float4*>(smem + t * YS + o * 64 + c4);
+      v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+      if (EPI == 1) {
+        const float4 r = *reinterpret_cast<const float4*>(res + pix * a.res_ld + c4);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      *reinterpret_cast<float4*>(out + pix * a.out_ld + c4) = v;
+    }
+  }
+}
+
+#endif  // SE3TN_TRUNK_REGV
+
 // in / res / out: padded NHWC tensors of the 44 x 44 maps; U: F(2x2) planes [chunk][16][64][32] per group (launch_wino_weights, m = 2)
 hipError_t launch_wino64(const float* in, int in_ld, int in_gs, const float* U, long long u_gs, const float* bias, int bias_gs,
                          const float* res, int res_ld, int res_gs, float* out, int out_ld, int out_gs, int n, int groups, int epi,
-                         hipStream_t st) {
+                         int variant, hipStream_t st) {
   Wino64Args a{};
   a.in = in; a.U = U; a.bias = bias; a.res = res; a.out = out;
   a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
   a.in_gs = in_gs; a.res_gs = res_gs; a.out_gs = out_gs; a.bias_gs = bias_gs; a.u_gs = u_gs;
   a.n = n; a.groups = groups;
-  static PerDeviceOnce attr0, attr1;
-  auto k0 = wino64_fused_kernel<0>;
-  auto k1 = wino64_fused_kernel<1>;
-  bool* done = (epi == 1 ? attr1 : attr0).current();
+  // variant 1: wino64_fused_kernel (V through LDS, barrier per step); 2: wino64_regv_kernel (V in registers, no barrier in the loop)
+  constexpr size_t lds2 = sizeof(float) * 2 * W64_PATCH_FLOATS;   // 147,456 B >= the epilogue's 125,840
+  static_assert(lds2 >= sizeof(float) * W64_YLDS_FLOATS, "the epilogue staging must fit the patch buffers");
+  static PerDeviceOnce attr[4];
+#if !SE3TN_TRUNK_REGV
+  variant = 1;   // the register-V experiment is not part of the default build
+#endif
+  const void* kern = epi == 1 ? reinterpret_cast<const void*>(wino64_fused_kernel<1>) : reinterpret_cast<const void*>(wino64_fused_kernel<0>);
+#if SE3TN_TRUNK_REGV
+  if (variant == 2) kern = epi == 1 ? reinterpret_cast<const void*>(wino64_regv_kernel<1>) : reinterpret_cast<const void*>(wino64_regv_kernel<0>);
+#endif
+  const size_t lds = variant == 2 ? lds2 : W64_LDS_BYTES;
+  bool* done = attr[(variant == 2 ? 2 : 0) + (epi == 1 ? 1 : 0)].current();
   if (!done || !*done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(epi == 1 ? k1 : k0), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)W64_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (done) *done = true;
   }
   const dim3 grid(n * 4 * groups);
-  if (epi == 1) hipLaunchKernelGGL(k1, grid, dim3(512), W64_LDS_BYTES, st, a);
-  else hipLaunchKernelGGL(k0, grid, dim3(512), W64_LDS_BYTES, st, a);
+#if SE3TN_TRUNK_REGV
+  if (variant == 2) {
+    if (epi == 1) hipLaunchKernelGGL(wino64_regv_kernel<1>, grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(wino64_regv_kernel<0>, grid, dim3(512), lds, st, a);
+    return hipGetLastError();
+  }
+#endif
+  if (epi == 1) hipLaunchKernelGGL(wino64_fused_kernel<1>, grid, dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(wino64_fused_kernel<0>, grid, dim3(512), lds, st, a);
   return hipGetLastError();
 }
 

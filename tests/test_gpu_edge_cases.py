@@ -237,11 +237,12 @@ def test_hipgraph_replay_matches_eager(se3):
     assert any(g for g in [graph.engine]) and graph._stream is not None
 
 
-def test_hipgraph_replay_of_the_winograd_path(se3):
-    """n = 8 >= SE3TN_WINOGRAD_DEFAULT_MIN_BATCH: the captured graph contains the Winograd transform and
-    GEMM kernels; replays are bit-identical to eager and follow new input data in the same buffers."""
+@pytest.mark.parametrize("n", [8, 64])
+def test_hipgraph_replay_of_the_winograd_path(se3, n):
+    """n = 8 >= SE3TN_WINOGRAD_DEFAULT_MIN_BATCH: the captured graph contains the Winograd transform and GEMM kernels (F(4x4) fused
+    blocks); n = 64: the F(6x6) fused blocks with the persistent 128 x 256 GEMM and the fused trunk kernel.  Replays are bit-identical
+    to eager and follow new input data in the same buffers."""
     sd = O.make_state_dict(0)
-    n = 8
     eng = se3.Engine(0, n)
     eng.load_state_dict(sd)
     assert eng.get_winograd()[0] <= n
