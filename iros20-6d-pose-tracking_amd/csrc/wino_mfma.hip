@@ -37,6 +37,17 @@
 #define WINO_MID_CS_H 32   // ... on the 11 x 11 maps (LDS 14 x 14 x CS floats)
 #endif
 
+#ifdef SE3TN_GEMMP_TRACE
+// diagnostic build only (scripts/gemmp_trace.py): waves of workgroup 0 of the last wino_gemmp_kernel launch stamp every K-step
+// [wave 8][k-step 64][5 stamps]: step start | DMA issued | MFMAs issued | vmcnt(0) passed | barrier passed   (s_memtime, shader clock)
+__device__ unsigned long long se3tn_gemmp_trace[8 * 64 * 5];
+extern "C" int se3tn_debug_gemmp_trace(void* host_out, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(se3tn_gemmp_trace), bytes, 0, hipMemcpyDeviceToHost);
+}
+#define GP_STAMP(K, I) if (blockIdx.x == 0 && lane == 0 && (K) < 64) ::se3tn_gemmp_trace[(wid * 64 + (K)) * 5 + (I)] = __builtin_amdgcn_s_memtime();
+#else
+#define GP_STAMP(K, I)
+#endif
 #ifdef SE3TN_WG_TRACE
 // diagnostic build only (scripts/wg_trace.py): every workgroup of wino_gemm_kernel records where and when it ran
 __device__ unsigned long long se3tn_wg_trace[8 * 4096];
@@ -618,18 +629,27 @@ __global__ __launch_bounds__(512, 2) void wino_gemm8_kernel(const WinoArgs a) {
 // b = (group, frequency) are consecutive slots of ONE XCD, so U_b and V_b cross that XCD's L2 once.
 // Same fragment layout, swizzle and k order as wino_gemm_kernel: bit-identical M.
 // -------------------------------------------------------------------------------------------------
-template <int CIN>
+#ifndef SE3TN_GEMMP_FRAG2
+#define SE3TN_GEMMP_FRAG2 0
+#endif
+// BM = 128: 2 x 4 waves of 64 x 64 (the shape described above).  BM = 256: 256 rows x 256 couts, 4 x 2 waves of 64 x 128 (8 accumulator
+// blocks per wave, 128 KB of LDS): twice the MFMAs per K-step barrier and per DMA byte (64 KB per 256 x 256 x 32 MACs); at batch 64 both
+// layer shapes are then exactly 256 tiles = ONE per CU.
+template <int CIN, int BM>
 __global__ __launch_bounds__(512, 2) void wino_gemmp_kernel(const WinoArgs a, int total_tiles) {
-  constexpr int PT = 2, CT = 2, BM = 128, BN = 256;
+  constexpr int BN = 256;
+  constexpr int WN = BM == 128 ? 4 : 2, PT = 2, CT = BN / (32 * WN);   // wave tile 64 rows x (64 | 128) couts
+  constexpr int VP = BM / 64;                                            // DMA pieces per thread for the V tile (U: 4)
   constexpr int NCH = CIN / 32;
   constexpr int BUF = (BM + BN) * 32;
+  static_assert(BM == 128 || BM == 256, "row tile");
   static_assert(NCH % 2 == 0, "the double buffer's parity must be the same at every tile start");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 2, wn = wid & 3;
+  const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, hh = lane >> 5;
   const int panels = a.Cout / BN, mtiles = (a.T + BM - 1) / BM, tpp = panels * mtiles;
   const int mlast = a.T - 1;
@@ -650,20 +670,19 @@ __global__ __launch_bounds__(512, 2) void wino_gemmp_kernel(const WinoArgs a, in
   };
   const float* Vb;
   const float* Ub;
-  unsigned pvoff[2];
+  unsigned pvoff[VP];
   auto set_tile = [&](int b, int m0, int n0) {
     const int g = b / a.nf, f = b - g * a.nf;
     Vb = a.V + (size_t)b * a.T * CIN;
     Ub = a.U + (size_t)g * a.u_gs + ((size_t)f * a.Cout + n0) * 32;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) pvoff[j] = (unsigned)((min(m0 + r0 + 64 * j, mlast) * CIN + c4 * 4) * 4);
+    for (int j = 0; j < VP; ++j) pvoff[j] = (unsigned)((min(m0 + r0 + 64 * j, mlast) * CIN + c4 * 4) * 4);
   };
 #define ISSUE_TILEP(CH, BUFI)                                                                        \
   {                                                                                                  \
     const float* pb_ = Vb + (CH) * 32;                                                               \
     const unsigned lb_ = lds0 + (unsigned)(((BUFI) * BUF + wid * 256) * 4);                          \
-    glds16<0>(pb_, pvoff[0], lb_);                                                                   \
-    glds16<0>(pb_, pvoff[1], lb_ + 8192);                                                            \
+    _Pragma("unroll") for (int j_ = 0; j_ < VP; ++j_) glds16<0>(pb_, pvoff[j_], lb_ + j_ * 8192);     \
     const float* tb_ = Ub + (size_t)(CH) * a.nf * a.Cout * 32;                                       \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) glds16<0>(tb_ + 2048 * j_, wvoff, lb_ + BM * 128 + j_ * 8192); \
   }
@@ -688,6 +707,8 @@ __global__ __launch_bounds__(512, 2) void wino_gemmp_kernel(const WinoArgs a, in
   ISSUE_TILEP(0, 0)
   wait_dma_and_barrier();
 
+  int kstep_ = 0;
+  (void)kstep_;
   while (true) {
     const int vn = v + gridDim.x;
     const bool more = vn < total_tiles;
@@ -695,6 +716,10 @@ __global__ __launch_bounds__(512, 2) void wino_gemmp_kernel(const WinoArgs a, in
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       const int buf = ch & 1;
+      GP_STAMP(kstep_, 0)
+      // (where the six DMA pieces of a wave are issued does not matter: all at the step start, as here, or spread between the MFMA
+      // groups, a K-step takes 9,690 cycles for 8,192 of matrix work; nor does alternating s_setprio between the two waves of a
+      // SIMD help -- profiles/r04_gemmp_trace.txt, EXPERIMENTS item 33)
       if (ch + 1 < NCH) {
         ISSUE_TILEP(ch + 1, buf ^ 1)
       } else if (more) {   // the next tile's first chunk rides under this tile's last K-step
@@ -702,19 +727,60 @@ __global__ __launch_bounds__(512, 2) void wino_gemmp_kernel(const WinoArgs a, in
         set_tile(b, m0, n0);
         ISSUE_TILEP(0, buf ^ 1)
       }
+      GP_STAMP(kstep_, 1)
       const float* pP = smem + buf * BUF + (wm * PT * 32 + l31) * 32;
       const float* pW = smem + buf * BUF + (BM + wn * CT * 32 + l31) * 32;
 #define FOG(G) ((G) == 0 ? fo0 : (G) == 1 ? fo1 : (G) == 2 ? fo2 : fo3)
 #define PXF(G) *reinterpret_cast<const float4*>(pP + i * 1024 + FOG(G))
 #define WTF(G) *reinterpret_cast<const float4*>(pW + j * 1024 + FOG(G))
+#if SE3TN_GEMMP_FRAG2
+      // fragments of 8-k group g + 1 are requested BEFORE the 16 | 32 MFMAs of group g are issued (two register sets; fences keep the
+      // order): a wave alone on its SIMD -- the second half of every K-step, profiles/r04_gemmp_trace.txt -- otherwise waits for its own
+      // ds_read_b128 every 8 MFMAs (72 instead of 64 cycles per MFMA)
+      {
+        float4 pvA[PT], wvA[CT], pvB[PT], wvB[CT];
+#define GP_LOADF(PV, WV, G)                                                     \
+        _Pragma("unroll") for (int i = 0; i < PT; ++i) PV[i] = PXF(G);             \
+        _Pragma("unroll") for (int j = 0; j < CT; ++j) WV[j] = WTF(G);
+#define GP_MMAF(PV, WV)                                                         \
+        _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[j].x, PV[i].x, acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[j].y, PV[i].y, acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[j].z, PV[i].z, acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[j].w, PV[i].w, acc[i][j], 0, 0, 0);
+        GP_LOADF(pvA, wvA, 0)
+        GP_LOADF(pvB, wvB, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        GP_MMAF(pvA, wvA)
+        __builtin_amdgcn_sched_barrier(0);
+        GP_LOADF(pvA, wvA, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        GP_MMAF(pvB, wvB)
+        __builtin_amdgcn_sched_barrier(0);
+        GP_LOADF(pvB, wvB, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        GP_MMAF(pvA, wvA)
+        __builtin_amdgcn_sched_barrier(0);
+        GP_MMAF(pvB, wvB)
+#undef GP_LOADF
+#undef GP_MMAF
+      }
+#else
       SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
       SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
       SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
       SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
+#endif
 #undef PXF
 #undef WTF
 #undef FOG
-      if (ch + 1 < NCH || more) wait_dma_and_barrier();
+      GP_STAMP(kstep_, 2)
+      if (ch + 1 < NCH || more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GP_STAMP(kstep_, 3)
+        __syncthreads();
+      }
+      GP_STAMP(kstep_, 4)
+      ++kstep_;
     }
     // lane holds row l31 x couts {8 q + 4 hh + 0..3} of each 32 x 32 block; the stores drain under the next tile's first K-step
     float* __restrict__ Mb = a.Mw + (size_t)cb * a.T * a.Cout;
@@ -1046,11 +1112,11 @@ static hipError_t launch_gemm8(const WinoArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int CIN>
+template <int CIN, int BM>
 static hipError_t launch_gemmp(const WinoArgs& a, int total_tiles, int grid, hipStream_t st) {
   static PerDeviceOnce attr;
-  auto kern = wino_gemmp_kernel<CIN>;
-  const size_t lds = 2 * (128 + 256) * 32 * sizeof(float);
+  auto kern = wino_gemmp_kernel<CIN, BM>;
+  const size_t lds = 2 * (BM + 256) * 32 * sizeof(float);
   bool* done = attr.current();
   if (!done || !*done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1061,6 +1127,12 @@ static hipError_t launch_gemmp(const WinoArgs& a, int total_tiles, int grid, hip
   return hipGetLastError();
 }
 
+#ifndef SE3TN_GEMMP_FRAG2
+#define SE3TN_GEMMP_FRAG2 0
+#endif
+#ifndef SE3TN_WINO_GEMMP_BM256
+#define SE3TN_WINO_GEMMP_BM256 0   // 1: 256 x 256 tiles when they give every CU a tile and the rows divide (batch 64: both layer shapes)
+#endif
 #ifndef SE3TN_WINO_GEMMP
 #define SE3TN_WINO_GEMMP 1   // 0: never take the persistent 128 x 256 kernel
 #endif
@@ -1081,7 +1153,11 @@ static hipError_t launch_gemm_auto(const WinoArgs& a, hipStream_t st) {
   if (SE3TN_WINO_GEMMP && a.gemmp != 0 && a.Cout % 256 == 0 && (a.groups * a.nf) % 8 == 0) {
     const int cus = a.num_cus > 0 ? a.num_cus : 256;
     const int tiles = (a.Cout / 256) * ((a.T + 127) / 128) * a.groups * a.nf;
-    if (a.gemmp == 1 || tiles >= 2 * cus) return launch_gemmp<CIN>(a, tiles, tiles < cus ? tiles : (cus / 8) * 8, st);
+    const int tiles2 = (a.Cout / 256) * ((a.T + 255) / 256) * a.groups * a.nf;
+    // a.gemmp: 2 | 3 force the 128- | 256-row form; 1 = whichever the rule below picks, whenever the shape allows
+    const bool big = a.gemmp == 3 || (a.gemmp != 2 && SE3TN_WINO_GEMMP_BM256 && tiles2 >= cus && a.T % 256 == 0);
+    if (big) return launch_gemmp<CIN, 256>(a, tiles2, tiles2 < cus ? tiles2 : (cus / 8) * 8, st);
+    if (a.gemmp >= 1 || tiles >= 2 * cus) return launch_gemmp<CIN, 128>(a, tiles, tiles < cus ? tiles : (cus / 8) * 8, st);
   }
   if (SE3TN_WINO_GEMM8 && q96 < q128) return launch_gemm8<CIN>(a, st);
   return q96 < q128 ? launch_gemm<CIN, 1, 4, 3, 1>(a, st) : launch_gemm<CIN, 2, 2, 2, 2>(a, st);
