@@ -311,7 +311,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
   if (const char* e = std::getenv("SE3TN_WINOGRAD_AUTO_TILE_AB2")) c->auto_tile_override[0] = (std::atoi(e) == 4 || std::atoi(e) == 6) ? std::atoi(e) : 0;
   if (const char* e = std::getenv("SE3TN_WINOGRAD_AUTO_TILE_HEADS")) c->auto_tile_override[1] = (std::atoi(e) == 4 || std::atoi(e) == 6) ? std::atoi(e) : 0;
   if (const char* e = std::getenv("SE3TN_TRUNK_KERNEL")) c->trunk_kernel = std::atoi(e) == 2 ? 2 : 1;
-  if (const char* e = std::getenv("SE3TN_WINO_GEMMP")) c->gemmp = (std::atoi(e) >= 0 && std::atoi(e) <= 3) ? std::atoi(e) : -1;
+  if (const char* e = std::getenv("SE3TN_WINO_GEMMP")) c->gemmp = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("SE3TN_WINOGRAD_FUSE")) c->wino_fuse = std::atoi(e) != 0;      // developer A/B switch (and the tests'
                                                                                                   // bit-equality check of the two forms)
   if (const char* e = std::getenv("SE3TN_TRUNK_WINOGRAD")) c->wino64_min_batch = std::atoi(e);   // developer A/B switch

@@ -629,20 +629,16 @@ __global__ __launch_bounds__(512, 2) void wino_gemm8_kernel(const WinoArgs a) {
 // b = (group, frequency) are consecutive slots of ONE XCD, so U_b and V_b cross that XCD's L2 once.
 // Same fragment layout, swizzle and k order as wino_gemm_kernel: bit-identical M.
 // -------------------------------------------------------------------------------------------------
-#ifndef SE3TN_GEMMP_FRAG2
-#define SE3TN_GEMMP_FRAG2 0
-#endif
-// BM = 128: 2 x 4 waves of 64 x 64 (the shape described above).  BM = 256: 256 rows x 256 couts, 4 x 2 waves of 64 x 128 (8 accumulator
-// blocks per wave, 128 KB of LDS): twice the MFMAs per K-step barrier and per DMA byte (64 KB per 256 x 256 x 32 MACs); at batch 64 both
-// layer shapes are then exactly 256 tiles = ONE per CU.
-template <int CIN, int BM>
+// (Measured and not kept -- profiles/r04_gemmp_trace.txt, EXPERIMENTS item 33, source in commit c7ec287: 256 x 256 tiles with 4 x 2 waves
+// of 64 x 128; fragments of the next 8-k group requested a group early; the DMA pieces spread between the MFMA groups; s_setprio
+// alternation between the two waves of a SIMD: all the same speed or slower.)
+template <int CIN>
 __global__ __launch_bounds__(512, 2) void wino_gemmp_kernel(const WinoArgs a, int total_tiles) {
-  constexpr int BN = 256;
-  constexpr int WN = BM == 128 ? 4 : 2, PT = 2, CT = BN / (32 * WN);   // wave tile 64 rows x (64 | 128) couts
-  constexpr int VP = BM / 64;                                            // DMA pieces per thread for the V tile (U: 4)
+  constexpr int BM = 128, BN = 256;
+  constexpr int WN = 4, PT = 2, CT = 2;   // 2 x 4 waves, wave tile 64 rows x 64 couts
+  constexpr int VP = BM / 64;             // DMA pieces per thread for the V tile (U: 4)
   constexpr int NCH = CIN / 32;
   constexpr int BUF = (BM + BN) * 32;
-  static_assert(BM == 128 || BM == 256, "row tile");
   static_assert(NCH % 2 == 0, "the double buffer's parity must be the same at every tile start");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -733,43 +729,10 @@ __global__ __launch_bounds__(512, 2) void wino_gemmp_kernel(const WinoArgs a, in
 #define FOG(G) ((G) == 0 ? fo0 : (G) == 1 ? fo1 : (G) == 2 ? fo2 : fo3)
 #define PXF(G) *reinterpret_cast<const float4*>(pP + i * 1024 + FOG(G))
 #define WTF(G) *reinterpret_cast<const float4*>(pW + j * 1024 + FOG(G))
-#if SE3TN_GEMMP_FRAG2
-      // fragments of 8-k group g + 1 are requested BEFORE the 16 | 32 MFMAs of group g are issued (two register sets; fences keep the
-      // order): a wave alone on its SIMD -- the second half of every K-step, profiles/r04_gemmp_trace.txt -- otherwise waits for its own
-      // ds_read_b128 every 8 MFMAs (72 instead of 64 cycles per MFMA)
-      {
-        float4 pvA[PT], wvA[CT], pvB[PT], wvB[CT];
-#define GP_LOADF(PV, WV, G)                                                     \
-        _Pragma("unroll") for (int i = 0; i < PT; ++i) PV[i] = PXF(G);             \
-        _Pragma("unroll") for (int j = 0; j < CT; ++j) WV[j] = WTF(G);
-#define GP_MMAF(PV, WV)                                                         \
-        _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[j].x, PV[i].x, acc[i][j], 0, 0, 0); \
-        _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[j].y, PV[i].y, acc[i][j], 0, 0, 0); \
-        _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[j].z, PV[i].z, acc[i][j], 0, 0, 0); \
-        _Pragma("unroll") for (int j = 0; j < CT; ++j) _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[j].w, PV[i].w, acc[i][j], 0, 0, 0);
-        GP_LOADF(pvA, wvA, 0)
-        GP_LOADF(pvB, wvB, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        GP_MMAF(pvA, wvA)
-        __builtin_amdgcn_sched_barrier(0);
-        GP_LOADF(pvA, wvA, 2)
-        __builtin_amdgcn_sched_barrier(0);
-        GP_MMAF(pvB, wvB)
-        __builtin_amdgcn_sched_barrier(0);
-        GP_LOADF(pvB, wvB, 3)
-        __builtin_amdgcn_sched_barrier(0);
-        GP_MMAF(pvA, wvA)
-        __builtin_amdgcn_sched_barrier(0);
-        GP_MMAF(pvB, wvB)
-#undef GP_LOADF
-#undef GP_MMAF
-      }
-#else
       SE3TN_MMA_GROUP(PT, CT, PXF(0), WTF(0))
       SE3TN_MMA_GROUP(PT, CT, PXF(1), WTF(1))
       SE3TN_MMA_GROUP(PT, CT, PXF(2), WTF(2))
       SE3TN_MMA_GROUP(PT, CT, PXF(3), WTF(3))
-#endif
 #undef PXF
 #undef WTF
 #undef FOG
@@ -1112,11 +1075,11 @@ static hipError_t launch_gemm8(const WinoArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int CIN, int BM>
+template <int CIN>
 static hipError_t launch_gemmp(const WinoArgs& a, int total_tiles, int grid, hipStream_t st) {
   static PerDeviceOnce attr;
-  auto kern = wino_gemmp_kernel<CIN, BM>;
-  const size_t lds = 2 * (BM + 256) * 32 * sizeof(float);
+  auto kern = wino_gemmp_kernel<CIN>;
+  const size_t lds = 2 * (128 + 256) * 32 * sizeof(float);
   bool* done = attr.current();
   if (!done || !*done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1127,12 +1090,6 @@ static hipError_t launch_gemmp(const WinoArgs& a, int total_tiles, int grid, hip
   return hipGetLastError();
 }
 
-#ifndef SE3TN_GEMMP_FRAG2
-#define SE3TN_GEMMP_FRAG2 0
-#endif
-#ifndef SE3TN_WINO_GEMMP_BM256
-#define SE3TN_WINO_GEMMP_BM256 0   // 1: 256 x 256 tiles when they give every CU a tile and the rows divide (batch 64: both layer shapes)
-#endif
 #ifndef SE3TN_WINO_GEMMP
 #define SE3TN_WINO_GEMMP 1   // 0: never take the persistent 128 x 256 kernel
 #endif
@@ -1153,11 +1110,7 @@ static hipError_t launch_gemm_auto(const WinoArgs& a, hipStream_t st) {
   if (SE3TN_WINO_GEMMP && a.gemmp != 0 && a.Cout % 256 == 0 && (a.groups * a.nf) % 8 == 0) {
     const int cus = a.num_cus > 0 ? a.num_cus : 256;
     const int tiles = (a.Cout / 256) * ((a.T + 127) / 128) * a.groups * a.nf;
-    const int tiles2 = (a.Cout / 256) * ((a.T + 255) / 256) * a.groups * a.nf;
-    // a.gemmp: 2 | 3 force the 128- | 256-row form; 1 = whichever the rule below picks, whenever the shape allows
-    const bool big = a.gemmp == 3 || (a.gemmp != 2 && SE3TN_WINO_GEMMP_BM256 && tiles2 >= cus && a.T % 256 == 0);
-    if (big) return launch_gemmp<CIN, 256>(a, tiles2, tiles2 < cus ? tiles2 : (cus / 8) * 8, st);
-    if (a.gemmp >= 1 || tiles >= 2 * cus) return launch_gemmp<CIN, 128>(a, tiles, tiles < cus ? tiles : (cus / 8) * 8, st);
+    if (a.gemmp == 1 || tiles >= 2 * cus) return launch_gemmp<CIN>(a, tiles, tiles < cus ? tiles : (cus / 8) * 8, st);
   }
   if (SE3TN_WINO_GEMM8 && q96 < q128) return launch_gemm8<CIN>(a, st);
   return q96 < q128 ? launch_gemm<CIN, 1, 4, 3, 1>(a, st) : launch_gemm<CIN, 2, 2, 2, 2>(a, st);
