@@ -1153,6 +1153,9 @@ static hipError_t launch_mid(const WinoArgs& a, float* keep, hipStream_t st) {
 #ifndef WINO6_MID_VEC
 #define WINO6_MID_VEC 1    // channels per thread of the F(6x6) mid transform: 1 = 512 threads on the 22 x 22 maps (8 waves per CU beside
 #endif                     // 86 KB of LDS), 2 = 256
+#ifndef WINO6_MID_CS_AB
+#define WINO6_MID_CS_AB 32 // ... on the 22 x 22 maps (LDS 26 x 26 x CS floats: 86 KB at 32 = one workgroup per CU; 16 -> three of 256 threads: measured equal)
+#endif
 #ifndef WINO6_MID_CS_H
 #define WINO6_MID_CS_H 64  // channels per workgroup of the F(6x6) mid transform on the 11 x 11 maps (LDS 14 x 14 x CS floats)
 #endif
@@ -1177,7 +1180,7 @@ hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* u
   e = ab ? launch_gemm_auto<256>(c1, st) : launch_gemm_auto<512>(c1, st);
   if (e != hipSuccess) return e;
   float* keep1 = keep_mid ? c1.out : nullptr;
-  if (c1.m == 6) e = ab ? launch_mid<6, 4, 32, WINO6_MID_VEC>(c1, keep1, st) : launch_mid<6, 2, WINO6_MID_CS_H, WINO6_MID_VEC>(c1, keep1, st);
+  if (c1.m == 6) e = ab ? launch_mid<6, 4, WINO6_MID_CS_AB, WINO6_MID_VEC>(c1, keep1, st) : launch_mid<6, 2, WINO6_MID_CS_H, WINO6_MID_VEC>(c1, keep1, st);
   else if (c1.split) e = ab ? launch_mid<4, 6, WINO_MID_CS_AB, 2, 1>(c1, keep1, st) : launch_mid<4, 3, WINO_MID_CS_H, 2, 1>(c1, keep1, st);
   else e = ab ? launch_mid<4, 6, WINO_MID_CS_AB, 2>(c1, keep1, st) : launch_mid<4, 3, WINO_MID_CS_H, 2>(c1, keep1, st);
   if (e != hipSuccess) return e;

@@ -55,6 +55,12 @@ int main(int argc, char** argv) {
   CHECK(se3tn_pack_weights(ctx));
   CHECK(se3tn_upload_weights(ctx, NULL));
   CHECK(se3tn_set_normalizers(ctx, 0.03, 5 * 3.14159265358979323846 / 180));
+  /* the round-4 switches from plain C: the reference's pinned NumPy rounding is the default; AUTO tile selection */
+  if (se3tn_get_offset_rule(ctx) != SE3TN_OFFSET_RULE_NUMPY1) { fprintf(stderr, "offset rule default\n"); return 1; }
+  CHECK(se3tn_set_offset_rule(ctx, SE3TN_OFFSET_RULE_NUMPY2));
+  CHECK(se3tn_set_offset_rule(ctx, SE3TN_OFFSET_RULE_NUMPY1));
+  CHECK(se3tn_set_winograd(ctx, SE3TN_WINOGRAD_DEFAULT_MIN_BATCH, SE3TN_WINOGRAD_TILE_6_4));
+  CHECK(se3tn_set_winograd(ctx, SE3TN_WINOGRAD_DEFAULT_MIN_BATCH, SE3TN_WINOGRAD_TILE_AUTO));
 
   const size_t img = (size_t)n * 4 * 176 * 176 * 4;
   float *hA = (float*)malloc(img), *hB = (float*)malloc(img);

@@ -251,6 +251,7 @@ def test_hipgraph_replay_of_the_winograd_path(se3, n):
     Ac, Bc = A.cuda(), B.cuda()
     eng.infer(Ac, Bc, n, se3.NCHW, tr, ro)
     want = (tr.clone(), ro.clone(), eng.logits(n).clone())
+    torch.cuda.synchronize()     # the context's workspaces are about to be used from another stream: one stream at a time per context
     st = torch.cuda.Stream()
     eng.enable_graphs(True)
     with torch.cuda.stream(st):
