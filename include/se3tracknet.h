@@ -16,7 +16,10 @@
  *     full-frame calls grow their scratch on a first un-reserved call with a larger frame (draining the device first);
  *     inside a stream capture they refuse with SE3TN_E_STATE instead -- call se3tn_reserve at start-up;
  *   - return value: 0 = ok, >0 = a hipError_t, <0 = SE3TN_E_*; se3tn_last_error() has the text;
- *   - one context per (process, device); a context is thread-compatible, not thread-safe.
+ *   - one context per (process, device); a context is thread-compatible, not thread-safe, and its compute calls share one set of
+ *     activation workspaces: issue them on ONE stream, or order the streams yourself (events / synchronisation) -- two se3tn_infer of
+ *     the same context in flight on two streams corrupt each other.  Throughput over several streams = one context per stream on a
+ *     shared weight blob (se3tn_bind_weights; the Python mirror's PipelinedEngine).
  */
 #ifndef SE3TRACKNET_H
 #define SE3TRACKNET_H
