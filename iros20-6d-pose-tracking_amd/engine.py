@@ -143,10 +143,10 @@ class Engine:
         return "numpy2" if self.lib.se3tn_get_offset_rule(self._h) == _lib.OFFSET_RULE_NUMPY2 else "numpy1"
 
     def set_winograd(self, min_batch, tile=0):
-        """Batches of n >= min_batch run the 256/512-channel stride-1 convs as Winograd F(tile x tile,3x3)
-        (float32; tile 2 | 4 | 6 | _lib.WINOGRAD_TILE_AUTO = 4 below 14 pairs, 6 from there; 0 = keep); min_batch 0 = always the direct
-        kernels.  Defaults:
-        SE3TN_WINOGRAD_DEFAULT_MIN_BATCH / _TILE of include/se3tracknet.h."""
+        """Batches of n >= min_batch run the 256/512-channel residual blocks as Winograd F(tile x tile,3x3) launch sequences (float32;
+        tile 2 | 4 | 6 | _lib.WINOGRAD_TILE_6_4 = 6 for the 256-channel block + 4 for the heads | _lib.WINOGRAD_TILE_AUTO = 4 below 14
+        pairs, from there 6 for the 256-channel block and -- while rot_normalizer <= 0.2 rad -- for the heads; 0 = keep the tile);
+        min_batch 0 = always the direct kernels.  Defaults: SE3TN_WINOGRAD_DEFAULT_MIN_BATCH / _TILE of include/se3tracknet.h."""
         check(self.lib.se3tn_set_winograd(self._h, int(min_batch), int(tile)), "se3tn_set_winograd")
 
     def set_trunk_winograd(self, min_batch, min_fill_percent=None):
