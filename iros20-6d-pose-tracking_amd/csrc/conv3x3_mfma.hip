@@ -404,7 +404,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_gather_s2_kernel(const Con
 
 // =================================================================================================
 // small-batch (latency) path: split-K.  At batch 1 the big-tile kernels above would occupy 8-64 of
-// the 256 CUs (M = 121..1936 rows), so the K dimension is cut into `slices` runs of 32-channel chunks
+// the 256 CUs (M = 121..1936 rows), so the K dimension -- cin / 32 chunks x 9 taps K-steps -- is cut into `slices` runs of
+// consecutive K-steps (round 4: runs of >= 3 (chunk, tap) steps instead of whole chunks: a K-step of these small grids is DMA-latency
+// bound, ~1.3-2.6 us, so the kernel's time is its number of SEQUENTIAL steps; 9 per workgroup before)
 // handled by different workgroups (128 px x {128|64} cout, 4 waves, per-tap gather on the
 // zero-bordered input, stride 1 or 2, either arithmetic mode).  Each workgroup stores its raw partial accumulators to
 // part[slice][group][M][cout]; conv_reduce_kernel sums the slices in a FIXED order (deterministic,
@@ -433,7 +435,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_splitk_kernel(const ConvArgs a
   const float* __restrict__ wgt = a.w + (size_t)g * a.w_gs + (size_t)n0 * 32;
   const int Wp = a.W + 2, Hp = a.H + 2, HoWo = a.Ho * a.Wo;
   const int mlast = a.M - 1;
-  const int cps = NCH / a.slices, ch0 = sl * cps, KT = cps * 9;
+  // K-steps (32-channel chunk, tap) are numbered ch * 9 + tap; slice sl takes KT consecutive ones (a.slices divides NCH * 9)
+  const int KT = NCH * 9 / a.slices, ks0 = sl * KT;
 
   const int r0 = tid >> 3;
   const int c4 = (tid & 7) ^ ((r0 >> 1) & 7);
@@ -475,10 +478,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_splitk_kernel(const ConvArgs a
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  ISSUE_TILE(ch0, 0, 0)
+  int ch = ks0 / 9, tap = ks0 - ch * 9;
+  ISSUE_TILE(ch, tap, 0)
   wait_dma_and_barrier();
 
-  int ch = ch0, tap = 0;
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
     if (++tap == 9) { tap = 0; ++ch; }
@@ -531,7 +534,8 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvArgs a, int 
   const size_t slice_stride = (size_t)a.groups * a.M * cout;
   const float* src = a.part + ((size_t)g * a.M + m) * cout + c;
   float4 v = *reinterpret_cast<const float4*>(src);
-  for (int s = 1; s < a.slices; ++s) {  // fixed order: deterministic
+#pragma unroll 8
+  for (int s = 1; s < a.slices; ++s) {  // fixed order: deterministic (unrolled: the loads of 8 slices are in flight together)
     const float4 u = *reinterpret_cast<const float4*>(src + s * slice_stride);
     v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
   }
@@ -641,19 +645,29 @@ static hipError_t launch_splitk(const ConvArgs& a, int epi, int outf, int resf, 
   return hipGetLastError();
 }
 
-// Split-K is used when the big-tile grid would leave most of the 256 CUs idle and the partial-sum
-// workspace is large enough; slices = the smallest power of two that yields >= 512 workgroups.
+// Split-K is used when the big-tile grid would leave most of the 256 CUs idle and the partial-sum workspace is large enough.
+// slices = the largest divisor of the K-step count (cin / 32 x 9) that leaves every workgroup >= SE3TN_SPLITK_MIN_STEPS K-steps and a
+// ONE-image launch <= 512 workgroups (two per CU): 6 / 12 / 24 / 24 / 48 slices of 3 steps for the 64-ch / convAB1 / convAB2 /
+// trans|rot conv1 / conv2 layers.  It is a function of the LAYER, not of the batch: every output element is summed in the same order
+// whatever n (a pair's result does not depend on how many pairs share the call), unless the workspace forces fewer slices.
+#ifndef SE3TN_SPLITK_MIN_STEPS
+#define SE3TN_SPLITK_MIN_STEPS 3   // measured at batch 1: 2 -> 280 us, 3 -> 268 us, 4 -> 276 us per forward (whole chunks before: 321 us)
+#endif
 static int pick_slices(const ConvArgs& a, int cin, int cout, int big_tile_rows, int bn_big) {
   const int big_blocks = ((a.M + big_tile_rows - 1) / big_tile_rows) * (cout / bn_big) * a.groups;
   if (big_blocks >= 200 || a.part == nullptr) return 0;
   const int bn = cout >= 128 ? 128 : 64;
-  const int base = ((a.M + 127) / 128) * (cout / bn) * a.groups;
-  const int nch = cin / 32;
-  int slices = 1;
-  while (slices < nch && base * slices < 512) slices *= 2;
+  const int base1 = ((a.Ho * a.Wo + 127) / 128) * (cout / bn) * a.groups;   // workgroups of one image, one slice
+  const int ks = cin / 32 * 9;
   const size_t per_slice = (size_t)a.groups * a.M * cout * sizeof(float);
-  while (slices > 1 && per_slice * slices > a.part_bytes) slices /= 2;
-  return per_slice * slices <= a.part_bytes ? slices : 0;
+  int best = 0;
+  for (int sl = 1; sl <= ks; ++sl) {
+    if (ks % sl != 0 || ks / sl < SE3TN_SPLITK_MIN_STEPS) continue;
+    if (per_slice * sl > a.part_bytes) break;
+    if (best > 0 && base1 * sl > 512) break;
+    best = sl;
+  }
+  return best;
 }
 
 // Slab sizes (pixels, multiple of 8) = worst case of
