@@ -646,25 +646,32 @@ static hipError_t launch_splitk(const ConvArgs& a, int epi, int outf, int resf, 
 }
 
 // Split-K is used when the big-tile grid would leave most of the 256 CUs idle and the partial-sum workspace is large enough.
-// slices = the largest divisor of the K-step count (cin / 32 x 9) that leaves every workgroup >= SE3TN_SPLITK_MIN_STEPS K-steps and a
-// ONE-image launch <= 512 workgroups (two per CU): 6 / 12 / 24 / 24 / 48 slices of 3 steps for the 64-ch / convAB1 / convAB2 /
-// trans|rot conv1 / conv2 layers.  It is a function of the LAYER, not of the batch: every output element is summed in the same order
-// whatever n (a pair's result does not depend on how many pairs share the call), unless the workspace forces fewer slices.
+// slices = the largest divisor of the K-step count (cin / 32 x 9) that leaves every workgroup >= SE3TN_SPLITK_MIN_STEPS K-steps and
+// the launch <= 512 workgroups (two per CU).  Up to SE3TN_SPLITK_FIXED_MAX_N images the workgroup count is taken from the ONE-image
+// geometry -- 6 / 12 / 24 / 24 / 48 slices of 3 steps for the 64-ch / convAB1 / convAB2 / trans|rot conv1 / conv2 layers -- so the
+// slice count is a function of the layer (the same summation order for one pair alone or two together); larger batches count the
+// real grid (fewer, longer slices), so from 3 pairs on a pair's last bits may depend on the batch it travels in -- as they do across
+// the algorithm switches at 6 / 14 pairs, and in the reference under cuDNN.
 #ifndef SE3TN_SPLITK_MIN_STEPS
 #define SE3TN_SPLITK_MIN_STEPS 3   // measured at batch 1: 2 -> 280 us, 3 -> 268 us, 4 -> 276 us per forward (whole chunks before: 321 us)
+#endif
+#ifndef SE3TN_SPLITK_FIXED_MAX_N
+#define SE3TN_SPLITK_FIXED_MAX_N 2  // (5 = up to the Winograd threshold was measured: 15 % slower at n = 4 -- 4 x the partial sums of 48 slices)
 #endif
 static int pick_slices(const ConvArgs& a, int cin, int cout, int big_tile_rows, int bn_big) {
   const int big_blocks = ((a.M + big_tile_rows - 1) / big_tile_rows) * (cout / bn_big) * a.groups;
   if (big_blocks >= 200 || a.part == nullptr) return 0;
   const int bn = cout >= 128 ? 128 : 64;
-  const int base1 = ((a.Ho * a.Wo + 127) / 128) * (cout / bn) * a.groups;   // workgroups of one image, one slice
+  const int hw = a.Ho * a.Wo;
+  const int rows = a.M <= SE3TN_SPLITK_FIXED_MAX_N * hw ? hw : a.M;          // one image's rows | the real grid
+  const int base = ((rows + 127) / 128) * (cout / bn) * a.groups;            // workgroups per slice
   const int ks = cin / 32 * 9;
   const size_t per_slice = (size_t)a.groups * a.M * cout * sizeof(float);
   int best = 0;
   for (int sl = 1; sl <= ks; ++sl) {
     if (ks % sl != 0 || ks / sl < SE3TN_SPLITK_MIN_STEPS) continue;
     if (per_slice * sl > a.part_bytes) break;
-    if (best > 0 && base1 * sl > 512) break;
+    if (best > 0 && base * sl > 512) break;
     best = sl;
   }
   return best;

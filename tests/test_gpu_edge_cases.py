@@ -192,8 +192,10 @@ def test_tracker_samples_gt_1_and_bind_blob_path(se3):
     rgb, depth = Fx.synthetic_frame(40)
     P0 = Fx.pose(3)
     P1 = trk.on_track(P0, rgb, depth, samples=1)
+    P2 = trk.on_track(P0, rgb, depth, samples=2)
     P4 = trk.on_track(P0, rgb, depth, samples=4)
-    assert (P1 == P4).all()
+    assert (P1 == P2).all()                      # one pair alone or two together: the same split-K partition, the same bits
+    assert np.abs(P1 - P4).max() < 1e-7          # from 3 pairs on the K partition follows the grid: float32 rounding only
     want, _ = O.on_track(sd, P0, rgb, depth, *Fx.synthetic_render(7, P0[2, 3]), Fx.K_YCB, 250.0, mean, std)
     assert np.abs(P1 - want).max() < 1e-5
     # same weights through pack -> (device copy standing in for the RCCL broadcast) -> bind
@@ -216,7 +218,10 @@ def test_on_track_batch_equals_sequential(se3):
     seq = np.stack([trk.on_track(poses[i], *frames[i]) for i in range(5)])
     bat = trk.on_track_batch(poses, [f[0] for f in frames], [f[1] for f in frames])
     assert bat.shape == (5, 4, 4)
-    assert np.abs(bat - seq).max() < 1e-9   # same kernels (small-batch path), fixed-order reductions
+    assert np.abs(bat - seq).max() < 1e-7   # same kernels (small-batch path), fixed-order reductions; the split-K partition of a
+                                            # 5-pair call differs from a 1-pair call's: float32 rounding (1e-8 class), deterministic
+    bat2 = trk.on_track_batch(poses, [f[0] for f in frames], [f[1] for f in frames])
+    assert (bat2 == bat).all()
     with pytest.raises(ValueError):
         trk.on_track_batch(poses * 2, [f[0] for f in frames] * 2, [f[1] for f in frames] * 2)
 
