@@ -655,6 +655,9 @@ static hipError_t launch_splitk(const ConvArgs& a, int epi, int outf, int resf, 
 #ifndef SE3TN_SPLITK_MIN_STEPS
 #define SE3TN_SPLITK_MIN_STEPS 3   // measured at batch 1: 2 -> 280 us, 3 -> 268 us, 4 -> 276 us per forward (whole chunks before: 321 us)
 #endif
+#ifndef SE3TN_SPLITK_MAX_WGS
+#define SE3TN_SPLITK_MAX_WGS 512
+#endif
 #ifndef SE3TN_SPLITK_FIXED_MAX_N
 #define SE3TN_SPLITK_FIXED_MAX_N 2  // (5 = up to the Winograd threshold was measured: 15 % slower at n = 4 -- 4 x the partial sums of 48 slices)
 #endif
@@ -671,7 +674,7 @@ static int pick_slices(const ConvArgs& a, int cin, int cout, int big_tile_rows, 
   for (int sl = 1; sl <= ks; ++sl) {
     if (ks % sl != 0 || ks / sl < SE3TN_SPLITK_MIN_STEPS) continue;
     if (per_slice * sl > a.part_bytes) break;
-    if (best > 0 && base * sl > 512) break;
+    if (best > 0 && base * sl > SE3TN_SPLITK_MAX_WGS) break;
     best = sl;
   }
   return best;
