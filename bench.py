@@ -404,7 +404,6 @@ def main():
         wino_tiles[key] = t_
         executed_per_pair += groups * 2 * cin * cout * ((t_ + 2) ** 2 * (-(-hw // t_)) ** 2 - 9 * hw * hw)
     wino_on = bool(wino_tiles)
-    wino_tile = max(wino_tiles.values()) if wino_tiles else 0     # (descriptions only: the per-launch tiles are in roofline.launches)
     wino_desc = "/".join("F(%dx%d)" % (t_, t_) for t_ in sorted(set(wino_tiles.values()), reverse=True))
     layers = eng.profile_launches(slots - 1)
     # the 64-channel trunk launches that took the fused Winograd F(2x2) kernel (the library decides per launch: whole rounds of

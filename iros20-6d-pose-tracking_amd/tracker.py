@@ -179,7 +179,6 @@ class Tracker:
         rgb_d = torch.from_numpy(np.ascontiguousarray(current_rgb)).to(dev, non_blocking=True)
         dep_d = torch.from_numpy(_depth_u16(current_depth, current_rgb)).to(dev, non_blocking=True)
         z_mm = float(prev_pose[2, 3]) * 1000
-        res = self.image_size[0]
         # the reference evaluates `samples` IDENTICAL hypotheses (only i == 0 sets sample_pose, predict.py:229-231)
         # and returns the first: any count beyond the engine's batch capacity adds nothing -- clamp, never overrun
         n = max(1, min(int(samples), self.engine.max_batch))
