@@ -99,6 +99,9 @@ def main():
                          "(tests/test_bench_launch.py: the N > 1 code path must have run somewhere before it meets RCCL)")
     args = ap.parse_args()
 
+    # the host driver of these boxes supports dmabuf IPC only: without this RCCL's buffer sharing between the ranks fails with
+    # hipIpcGetMemHandle "invalid argument".  Exported by the image already; set here too, before the HIP runtime loads.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
