@@ -53,6 +53,7 @@ def test_dropin_driver_writes_what_the_reference_driver_writes(golden, tmp_path)
             return golden["rgbA"][i], golden["depthA"][i]
     trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=OBJECT_WIDTH), mean, std, {"state_dict": sd}, renderer=ReferenceImageA(),
                       trans_normalizer=0.03, rot_normalizer=30 * np.pi / 180)
+    trk.engine.set_offset_rule("numpy2")       # like for like: the golden is the reference's driver under NumPy 2 (this image's interpreter)
     out = str(tmp_path / "res" / VIDEO)
     res = se3.sequence.predict_sequence_ycbineoat(trk, video, out)
     assert sorted(os.listdir(out)) == [str(f) for f in golden["files"]]

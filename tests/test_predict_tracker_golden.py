@@ -73,6 +73,8 @@ def test_dropin_tracker_vs_predict_tracker(golden):
             return golden["rgbA"][frame[0]], golden["depthA"][frame[0]]
     trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=OBJECT_WIDTH), mean, std, {"state_dict": sd}, renderer=ReferenceImageA())
     hip = se3.Tracker(dict(Fx.DATASET_INFO, object_width=OBJECT_WIDTH), mean, std, {"state_dict": sd})
+    for t in (trk, hip):
+        t.engine.set_offset_rule("numpy2")     # like for like: the golden is predict.Tracker under NumPy 2 (this image's interpreter)
     hip.renderer = se3.HipRenderer(hip.engine, Fx.icosphere(*MESH))
     worst = worst_hip = 0.0
     for f in range(FRAMES):
