@@ -280,58 +280,97 @@ hipError_t launch_stem(const float* inA, const float* inB, const float* w, const
 }
 
 // MaxPool2d(kernel 3, stride 2, padding 1) on [n,88,88,128] -> the interior of the zero-bordered
-// [n,46,46,128] tensor the 64-channel convs read; the pool's own padding is -inf (never wins), so
-// its input keeps explicit bounds.  One thread per (output pixel, 4 channels).
-__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ in,
-                                                            float* __restrict__ out, int total, int split_out) {
-  // workgroup -> (image, 8-pixel run): consecutive workgroup ids land on different XCDs (id % 8), but output rows p and
-  // p + 1 share the input row 2p + 1 -- so each XCD gets whole images (image = 8 k + xcd): the shared rows are then
-  // re-read from that XCD's own L2 instead of from HBM / Infinity Cache
-  constexpr int WPI = S2 * S2 * 32 / 256;      // 242 workgroups per image
+// [n,46,46,128] tensor the 64-channel convs read; the pool's own padding is -inf (never wins).
+// A streaming pass: 254 MB in, 68 MB out at batch 64, bound by what the memory system gives a pass that reads every byte once
+// (scripts/probes/hbm_stream.hip: 54 us for this shape, a write of 256 MB then a 4 : 1 read-back).  So every input element is
+// loaded by ONE thread (+ 1 / 8 of the columns and one halo row per strip twice): a thread owns 4 neighbouring output
+// columns x 4 channels (9 input columns), takes the horizontal maxima of an input row in registers and walks down a strip
+// of output rows, carrying the odd row it shares with the next output row.  One workgroup = one (image, strip): the 11 column
+// groups x 32 channel quads; the shared columns meet in that CU's L1.  max is exact: the order of the comparisons is free.
+constexpr int POOL_QG = S2 / 4;                 // 11 groups of 4 output columns
+constexpr int POOL_THREADS = POOL_QG * 32;      // 352
+static_assert(S1 == 2 * S2 && S2 % 4 == 0, "pool geometry");
+
+__device__ __forceinline__ float4 max4(const float4 a, const float4 b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
+// horizontal 3-maxima of input row y for the thread's 4 outputs (input columns x0 .. x0 + 8, x0 = -1 for the first group)
+__device__ __forceinline__ void pool_row(const float* __restrict__ src, int y, int x0, bool left, float4 hm[4]) {
+  const float* p = src + (size_t)y * S1 * 128;
+  float4 h[9];
+  h[0] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  if (left) h[0] = *reinterpret_cast<const float4*>(p + x0 * 128);
+#pragma unroll
+  for (int j = 1; j < 9; ++j) h[j] = *reinterpret_cast<const float4*>(p + (x0 + j) * 128);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) hm[k] = max4(max4(h[2 * k], h[2 * k + 1]), h[2 * k + 2]);
+}
+
+__global__ __launch_bounds__(POOL_THREADS) void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                     int n, int rows, int split_out) {
+  // workgroup -> (image, strip).  Consecutive workgroup ids land on different XCDs (id % 8); strips s and s + 1 share
+  // one input row, so an XCD gets whole images (image = 8 k + xcd) and the shared row comes from its own L2
+  const int strips = S2 / rows;
   int blk = blockIdx.x;
-  const int full = (total / (WPI * 256)) / 8 * 8;          // images covered by the remapped part
-  if (blk < full * WPI) {
+  const int full = n / 8 * 8;
+  if (blk < full * strips) {
     const int xcd = blk & 7, seq = blk >> 3;
-    blk = ((seq / WPI) * 8 + xcd) * WPI + seq % WPI;
+    blk = ((seq / strips) * 8 + xcd) * strips + seq % strips;
   }
-  const int idx = blk * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int c4 = idx & 31;
-  const int pix = idx >> 5;
-  const int n = pix / (S2 * S2), rem = pix - n * (S2 * S2);
-  const int po = rem / S2, qo = rem - po * S2;
-  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  const int img = blk / strips, strip = blk - img * strips;
+  const int c4 = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const float* src = in + (size_t)img * S1 * S1 * 128 + c4 * 4;
+  const int x0 = 8 * g - 1;
+  const bool left = g > 0;
+  const int po0 = strip * rows;
+  float4 carry[4];
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy) {
-    const int y = 2 * po + dy;
-    if ((unsigned)y >= (unsigned)S1) continue;
+  for (int k = 0; k < 4; ++k) carry[k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  if (po0 > 0) pool_row(src, 2 * po0 - 1, x0, left, carry);
+  for (int r = 0; r < rows; ++r) {
+    const int po = po0 + r;
+    float4 a[4], b[4];
+    pool_row(src, 2 * po, x0, left, a);
+    pool_row(src, 2 * po + 1, x0, left, b);
+    float* dst = out + ((size_t)(img * (S2 + 2) + po + 1) * (S2 + 2) + 4 * g + 1) * 128;
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int x = 2 * qo + dx;
-      if ((unsigned)x >= (unsigned)S1) continue;
-      const float4 v = *reinterpret_cast<const float4*>(in + ((size_t)(n * S1 + y) * S1 + x) * 128 + c4 * 4);
-      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    for (int k = 0; k < 4; ++k) {
+      const float4 m = max4(max4(carry[k], a[k]), b[k]);
+      carry[k] = b[k];
+      if (split_out) {  // f16x3 mode: 32-channel chunk = 32 f16 hi | 32 f16 lo (SELU output is bounded below, finite)
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        const int c = c4 * 4;
+        unsigned char* p_ = reinterpret_cast<unsigned char*>(dst + k * 128) + (c >> 5) * 128 + (c & 31) * 2;
+        const float f[4] = {m.x, m.y, m.z, m.w};
+        half4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (_Float16)f[e]; l[e] = (_Float16)(f[e] - (float)h[e]); }
+        *reinterpret_cast<half4*>(p_) = h;
+        *reinterpret_cast<half4*>(p_ + 64) = l;
+      } else {
+        *reinterpret_cast<float4*>(dst + k * 128 + c4 * 4) = m;
+      }
     }
-  }
-  float* dst = out + ((size_t)(n * (S2 + 2) + po + 1) * (S2 + 2) + qo + 1) * 128;
-  if (split_out) {  // f16x3 mode: 32-channel chunk = 32 f16 hi | 32 f16 lo (SELU output is bounded below, finite)
-    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-    const int c = c4 * 4;
-    unsigned char* p_ = reinterpret_cast<unsigned char*>(dst) + (c >> 5) * 128 + (c & 31) * 2;
-    const float f[4] = {m.x, m.y, m.z, m.w};
-    half4 h, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { h[e] = (_Float16)f[e]; l[e] = (_Float16)(f[e] - (float)h[e]); }
-    *reinterpret_cast<half4*>(p_) = h;
-    *reinterpret_cast<half4*>(p_ + 64) = l;
-  } else {
-    *reinterpret_cast<float4*>(dst + c4 * 4) = m;
   }
 }
 
+// Output rows per strip: the longest strips (fewest halo rows, longest streams) that still give every one of the 256 CUs a
+// workgroup.  Measured at batch 64 (profiles/EXPERIMENTS.md item 37): 11 rows = 256 workgroups 51.9 us; 4 rows = 704 workgroups
+// (2.75 per CU) 59.7; 22 rows = 128 workgroups 77.1; 2 / 1 rows 66 / 65; the one-pixel-per-thread kernel before it 70.6.
+// SE3TN_POOL_ROWS (developer switch, read once) forces a divisor of 44.
+static int pool_rows(int n) {
+  static const int forced = [] { const char* e = getenv("SE3TN_POOL_ROWS"); return e ? atoi(e) : 0; }();
+  if (forced > 0 && S2 % forced == 0) return forced;
+  const int divs[] = {44, 22, 11, 4, 2, 1};
+  for (int r : divs)
+    if (n * (S2 / r) >= 256) return r;
+  return 1;
+}
+
 hipError_t launch_maxpool(const float* in, float* out, int n, int split_out, hipStream_t st) {
-  const int total = n * S2 * S2 * 32;
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, out, total, split_out);
+  const int rows = pool_rows(n);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(n * (S2 / rows)), dim3(POOL_THREADS), 0, st, in, out, n, rows, split_out);
   return hipGetLastError();
 }
 
