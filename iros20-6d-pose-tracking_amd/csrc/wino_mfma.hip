@@ -273,6 +273,22 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoArgs a) {
   const int Hp = a.H + 2, Wp = a.W + 2;
   const float* __restrict__ src = a.Mw + ((size_t)g * a.nf * a.T + id.t) * a.Cout + id.cv * VEC;
   const size_t fs = (size_t)a.T * a.Cout;
+  // The residual of the whole tile is requested BEFORE the planes: inside the per-pixel loop below (a branch and a store per
+  // pixel) each of the M x M reads waited out its own memory latency, one after the other (EXPERIMENTS item 38).  Pixels past
+  // the map edge read a clamped (valid) address and are dropped with their outputs.
+  float rr[M][M][VEC];
+  if constexpr (EPI == 1 && SP == 0) {
+    const float* __restrict__ res0 = a.res + (size_t)g * a.res_gs + id.cv * VEC;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        int oy = M * id.ty + i, ox = M * id.tx + j;
+        oy = oy < a.H ? oy : a.H - 1; ox = ox < a.W ? ox : a.W - 1;
+        const vec v = *reinterpret_cast<const vec*>(res0 + (size_t)((id.n * Hp + oy + 1) * Wp + ox + 1) * a.res_ld);
+        __builtin_memcpy(rr[i][j], &v, sizeof(v));
+      }
+  }
   float u[M][N][VEC];  // A^T m, one column s at a time
 #pragma unroll
   for (int s = 0; s < N; ++s) {
@@ -301,6 +317,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoArgs a) {
   const float* __restrict__ res = (EPI == 1) ? a.res + (size_t)g * a.res_gs + (SP ? 0 : id.cv * VEC) : nullptr;
   float* __restrict__ out = a.out + (size_t)g * a.out_gs + (SP ? 0 : id.cv * VEC);
   bool bad = false;
+  // every read of this thread has landed before the first store: inside the per-pixel branches the compiler cannot count the
+  // stores in flight, so a later first use of a loaded register would become `s_waitcnt vmcnt(0)` = wait for the previous store
+  if constexpr (SP == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
 #pragma unroll
   for (int i = 0; i < M; ++i)
 #pragma unroll
@@ -313,8 +332,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoArgs a) {
         if (SP) {
           load_split_vec<VEC>(res, pix, a.res_ld, id.cv * VEC, r);
         } else {
-          const vec v = *reinterpret_cast<const vec*>(res + pix * a.res_ld);
-          __builtin_memcpy(r, &v, sizeof(v));
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) r[e] = rr[i][j][e];
         }
       }
       float o[VEC];
@@ -932,6 +951,18 @@ __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_ta
     const float* __restrict__ res = a.res + (size_t)g * a.res_gs + (SP ? 0 : c);
     float* __restrict__ kp = keep ? keep + (size_t)g * a.out_gs + c : nullptr;   // always float32 (f16x3 mode: head_f)
     const float2 b = *reinterpret_cast<const float2*>(a.bias + (size_t)g * a.bias_gs + c);
+    // the tile's residual, requested before the planes (see wino_output_kernel); clamped address past the map edge
+    float2 rr[M][M];
+    if constexpr (SP == 0) {
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          int oy = M * ty + i, ox = M * tx + j;
+          oy = oy < a.H ? oy : a.H - 1; ox = ox < a.W ? ox : a.W - 1;
+          rr[i][j] = *reinterpret_cast<const float2*>(res + (size_t)((n * Hp + oy + 1) * Wp + ox + 1) * a.res_ld);
+        }
+    }
     float u[M][N][2];
 #pragma unroll
     for (int s = 0; s < N; ++s) {
@@ -966,7 +997,7 @@ __global__ __launch_bounds__(((TH * TH * (CS / 2) + 63) / 64) * 64) void wino_ta
           load_split_vec<2>(res, pix, a.res_ld, c, rr);
           r = make_float2(rr[0], rr[1]);
         } else {
-          r = *reinterpret_cast<const float2*>(res + pix * a.res_ld);
+          r = rr[i][j];
         }
         float o[2];
 #pragma unroll
