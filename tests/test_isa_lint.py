@@ -38,3 +38,48 @@ def test_built_library_is_clean():
     kernels, bad = m.lint(LIB)
     assert kernels >= 60, "the disassembly found only %d kernels: the lint is not looking at the library" % kernels
     assert not bad, "kernels with a src1/src2 op_sel on a packed-f32 instruction: %s" % {k: v[0] for k, v in bad.items()}
+
+
+def _chains_module():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    spec = importlib.util.spec_from_file_location("isa_chains", os.path.join(ROOT, "scripts", "isa_chains.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_chain_figures_of_a_sequence():
+    m = _chains_module()
+    # 3 reads waited together, then `read -> wait -> store` four times, then a wait that only has a store before it
+    seq = ["L", "L", "L", "w0", "b", "L", "w0", "S", "b", "L", "w0", "S", "b", "L", "w0", "S", "L", "w1", "w0", "S", "w0"]
+    assert m.figures(seq) == (5, 3, 1)
+    assert m.figures(["D"] * 10 + ["w0", "|"]) == (1, 10, 0)
+    assert m.figures([]) == (0, 0, 0)
+
+
+def test_streaming_passes_of_the_float32_batch_path_keep_their_reads_in_flight():
+    """profiles/EXPERIMENTS.md item 38: the F(6x6) out-transform and tail issued one residual read per wait (36 dependent memory
+    latencies per thread) until the reads were hoisted; a refactoring that puts a read back inside the per-pixel branch shows up
+    here, in the disassembly, not in any parity test."""
+    m = _chains_module()
+    if not (os.path.exists(os.path.join(m.LLVM, "llvm-objdump")) and os.path.exists(LIB)):
+        pytest.skip("needs the ROCm LLVM tools and the built library")
+    seqs = m.sequences(LIB)
+    names = m.demangle(list(seqs))
+    by_name = {names[k].replace("se3tn::", "").replace("void ", "").split("(")[0]: m.figures(v) for k, v in seqs.items()}
+    want = {  # kernel: (most chains, fewest reads in flight at the widest point)
+        "wino_input_kernel<6, 2, 0>": (2, 60),
+        "wino_mid_kernel<6, 4, 32, 1, 0>": (2, 60),
+        "wino_mid_kernel<6, 2, 64, 1, 0>": (2, 60),
+        "wino_output_kernel<6, 2, 1, 0>": (6, 36),
+        "wino_tail_kernel<6, 2, 64, 0>": (6, 36),
+        "wino_output_kernel<4, 2, 1, 0>": (6, 16),
+        "wino_tail_kernel<4, 3, 64, 0>": (6, 16),
+        "maxpool3x3s2_kernel": (4, 16),
+    }
+    missing = [k for k in want if k not in by_name]
+    assert not missing, "kernels not found in the library: %s (have e.g. %s)" % (missing, sorted(by_name)[:5])
+    for k, (max_chains, min_inflight) in want.items():
+        chains, inflight, _ = by_name[k]
+        assert chains <= max_chains and inflight >= min_inflight, (k, chains, inflight)
