@@ -216,6 +216,14 @@ void se3tn_mesh_destroy(se3tn_mesh* mesh);
  * Outputs (device): rgb uint8 [176,176,3], depth uint16 [176,176] millimetres, 0 = background. */
 int se3tn_render(se3tn_ctx* ctx, se3tn_mesh* mesh, const double ob_in_cam[16], const double K[9],
                  const int32_t window[4], uint8_t* rgb, uint16_t* depth, void* stream);
+/* Rasterisation rule.  OpenGL leaves sub-pixel precision, interpolation arithmetic and float -> unorm rounding to the
+ * implementation; image A is defined here as what the reference's VispyRenderer produces on the conformant software GL the
+ * goldens were rendered on (tests/golden/gl_swiftshader*.npz), reproduced byte for byte: window coordinates snapped to
+ * 1 / 2^sub_bits pixel (4 = that implementation = the GL minimum GL_SUBPIXEL_BITS, default; 8 = what desktop GPUs report),
+ * integer top-left coverage, that implementation's plane-equation arithmetic and 16-bit unorm conversion.  The depth read-back
+ * (vispy_renderer.py:163-169) mixes a float32 array with float64 scalars: it follows se3tn_set_offset_rule's NumPy generation. */
+int se3tn_set_raster_rule(se3tn_ctx* ctx, int sub_bits);
+int se3tn_get_raster_rule(const se3tn_ctx* ctx);
 
 /* The reference's second renderer, offscreen_renderer.py:48-83 (pyrender; dataset_info['renderer'] == 'pyrenderer',
  * predict.py:161-164, textured .obj models): a FULL W x H camera frame, ambient light only, depth = camera z.

@@ -95,6 +95,7 @@ struct se3tn_ctx {
   int wino_us_tile = 0;
   int prec = SE3TN_PREC_F32;                    // se3tn_set_precision
   int offset_rule = SE3TN_OFFSET_RULE_NUMPY1;   // se3tn_set_offset_rule
+  int raster_sub_bits = 4;                      // se3tn_set_raster_rule: sub-pixel bits of the rasteriser's window coordinates
   int in_split[2] = {0, 0};                     // pixel format currently held by inA / inB
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
   int* overflow = nullptr;                      // device flag: a split-row store left the f16 range
@@ -122,8 +123,10 @@ struct se3tn_ctx {
 struct se3tn_mesh {
   float *verts = nullptr, *normals = nullptr, *colors = nullptr;
   int* faces = nullptr;
-  float4* vwin = nullptr;
+  float4* vpost = nullptr;  // [V] clip positions, [V] snapped window coordinates (raster_vertex_kernel)
+  int4* vsnap = nullptr;
   int* big = nullptr;     // [1 + F] queue of large triangles (raster_big_kernel)
+  int* clipq = nullptr;   // [1 + F] queue of triangles that cross the frustum (raster_clip_kernel)
   int V = 0, F = 0;
   // pyrender-style material (se3tn_mesh_set_texture): uv per vertex, RGB mip pyramid, Kd
   float* uv = nullptr;
@@ -893,7 +896,8 @@ int se3tn_mesh_create(se3tn_ctx* c, const float* verts, const float* normals, co
   struct { void** p; const void* src; size_t bytes; } up[] = {
       {(void**)&m->verts, verts, sizeof(float) * 3 * V},     {(void**)&m->normals, normals, sizeof(float) * 3 * V},
       {(void**)&m->colors, colors01, sizeof(float) * 3 * V}, {(void**)&m->faces, faces, sizeof(int) * 3 * F},
-      {(void**)&m->vwin, nullptr, sizeof(float4) * V},       {(void**)&m->big, nullptr, sizeof(int) * (1 + (size_t)F)}};
+      {(void**)&m->vpost, nullptr, sizeof(float4) * V},      {(void**)&m->vsnap, nullptr, sizeof(int4) * V},
+      {(void**)&m->big, nullptr, sizeof(int) * (1 + (size_t)F)}, {(void**)&m->clipq, nullptr, sizeof(int) * (1 + (size_t)F)}};
   for (auto& u : up) {
     hipError_t e = hipMalloc(u.p, u.bytes);
     if (e == hipSuccess && u.src) e = hipMemcpy(*u.p, u.src, u.bytes, hipMemcpyHostToDevice);
@@ -953,11 +957,38 @@ int se3tn_mesh_set_texture(se3tn_mesh* m, const float* uv, const uint8_t* rgb, i
 
 void se3tn_mesh_destroy(se3tn_mesh* m) {
   if (!m) return;
-  void* bufs[] = {m->verts, m->normals, m->colors, m->faces, m->vwin, m->big, m->uv, m->tex};
+  void* bufs[] = {m->verts, m->normals, m->colors, m->faces, m->vpost, m->vsnap, m->big, m->clipq, m->uv, m->tex};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete m;
 }
+
+// what both renderers share
+static void raster_common(RasterArgs& a, se3tn_ctx* c, se3tn_mesh* m, uint8_t* rgb, uint16_t* depth) {
+  a.verts = m->verts; a.normals = m->normals; a.colors = m->colors; a.faces = m->faces; a.vpost = m->vpost; a.vsnap = m->vsnap;
+  a.zbuf = c->zbuf; a.big = m->big; a.clipq = m->clipq; a.rgb = rgb; a.depth = depth; a.V = m->V; a.F = m->F;
+  a.numpy_rule = c->offset_rule; a.sub_bits = c->raster_sub_bits;
+}
+// proj * view as the vertex shader evaluates it (vispy_renderer.py:92): per column of the result, products accumulated left to
+// right in float32, never fused (volatile keeps the host compiler from contracting or re-associating)
+static void raster_pv(RasterArgs& a, const float P[4][4], const float V[4][4]) {
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 4; ++r) {
+      volatile float acc = P[r][0] * V[0][j];
+      for (int k = 1; k < 4; ++k) {
+        volatile float prod = P[r][k] * V[k][j];
+        acc = acc + prod;
+      }
+      a.PV[4 * r + j] = acc;
+    }
+}
+
+int se3tn_set_raster_rule(se3tn_ctx* c, int sub_bits) {
+  if (!c || (sub_bits != 4 && sub_bits != 8)) return fail(SE3TN_E_ARG, "se3tn_set_raster_rule: sub-pixel bits must be 4 or 8");
+  c->raster_sub_bits = sub_bits;
+  return SE3TN_OK;
+}
+int se3tn_get_raster_rule(const se3tn_ctx* c) { return c ? c->raster_sub_bits : -1; }
 
 int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const double K[9], const int32_t window[4],
                  uint8_t* rgb, uint16_t* depth, void* stream) {
@@ -965,19 +996,44 @@ int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const 
     return fail(SE3TN_E_ARG, "se3tn_render: bad argument");
   if (window[2] <= window[0] || window[3] <= window[1]) return fail(SE3TN_E_ARG, "se3tn_render: empty window");
   RasterArgs a{};
-  a.verts = m->verts; a.normals = m->normals; a.colors = m->colors; a.faces = m->faces; a.vwin = m->vwin;
-  a.zbuf = c->zbuf; a.big = m->big; a.rgb = rgb; a.depth = depth; a.V = m->V; a.F = m->F;
+  raster_common(a, c, m, rgb, depth);
   a.rw = RES; a.rh = RES; a.mode = 0;
-  for (int i = 0; i < 12; ++i) a.M[i] = (float)ob_in_cam[i];
-  a.fx = (float)K[0]; a.fy = (float)K[4]; a.cx = (float)K[2]; a.cy = (float)K[5];
-  a.left = (float)window[0]; a.top = (float)window[1]; a.right = (float)window[2]; a.bottom = (float)window[3];
-  // light_direction = (inv(ob2cam_gl^T) . [0, 0.1, -0.9, 1])[:3]  (vispy_renderer.py:172), float64 on the host.
-  // ob2cam_gl = diag(1,-1,-1,1) . ob_in_cam = [R' t'; 0 1];  inv(G^T) = (G^-1)^T = [R' 0; -t'^T R' 1]
-  // (G^-1 = [R'^T, -R'^T t'; 0 1]), so the first three components are R' . (0, 0.1, -0.9).
-  const double sgn[3] = {1.0, -1.0, -1.0};
-  const double l[3] = {0.0, 0.1, -0.9};
+  // The float32 uniforms the reference uploads, formed as it forms them (float64 numpy, then the cast of the upload):
+  // update_cam_mat (vispy_renderer.py:135-150): ortho (rounded to float32 FIRST, :146) . proj in float64 ...
+  const double n = R_NEAR_D, f = R_FAR_D;
+  const double left = window[0], top = window[1], right = window[2], bottom = window[3];
+  const double o00 = (double)(float)(2.0 / (right - left)), o03 = (double)(float)(-(right + left) / (right - left));
+  const double o11 = (double)(float)(2.0 / (top - bottom)), o13 = (double)(float)(-(top + bottom) / (top - bottom));
+  const double o22 = (double)(float)(-2.0 / (f - n)), o23 = (double)(float)(-(f + n) / (f - n));
+  double OP[4][4] = {{o00 * K[0], 0.0, o00 * -K[2] + o03 * -1.0, 0.0},
+                     {0.0, o11 * K[4], o11 * -K[5] + o13 * -1.0, 0.0},
+                     {0.0, 0.0, o22 * (n + f) + o23 * -1.0, o22 * (n * f)},
+                     {0.0, 0.0, -1.0, 0.0}};
+  a.dA = OP[2][2]; a.dB = OP[2][3];   // projection_matrix[2,2], [3,2] of the stored TRANSPOSE (:149, :163-164)
+  // ... view = ob2cam_gl = inv(glcam_in_cvcam) . ob_in_cam = diag(1,-1,-1,1) . ob_in_cam (predict.py:202-207), exact in float64
+  float P32[4][4], V32[4][4];
+  const double sgn[4] = {1.0, -1.0, -1.0, 1.0};
+  for (int r = 0; r < 4; ++r)
+    for (int q = 0; q < 4; ++q) {
+      P32[r][q] = (float)OP[r][q];
+      V32[r][q] = (float)(sgn[r] * ob_in_cam[4 * r + q]);
+    }
+  raster_pv(a, P32, V32);
+  // light_direction = (inv(ob2cam_gl^T) . [0, 0.1, -0.9, 1])[:3] (vispy_renderer.py:172) in float64.  With G = [R' t'; 0 1]:
+  // inv(G^T) = [inv(R'^T) 0; * 1], so the first three components are inv(R')^T . (0, 0.1, -0.9) -- a true inverse (adjugate /
+  // determinant), not R' itself: poses composed over many frames are orthonormal only to float32 rounding.
+  double R[3][3], adjT[3][3];
   for (int r = 0; r < 3; ++r)
-    a.light[r] = (float)(sgn[r] * (ob_in_cam[4 * r] * l[0] + ob_in_cam[4 * r + 1] * l[1] + ob_in_cam[4 * r + 2] * l[2]));
+    for (int q = 0; q < 3; ++q) R[r][q] = sgn[r] * ob_in_cam[4 * r + q];
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) {   // cofactor (r, q) = entry (r, q) of adj(R)^T = det(R) inv(R)^T
+      const int r1 = (r + 1) % 3, r2 = (r + 2) % 3, q1 = (q + 1) % 3, q2 = (q + 2) % 3;
+      adjT[r][q] = R[r1][q1] * R[r2][q2] - R[r1][q2] * R[r2][q1];
+    }
+  const double det = R[0][0] * adjT[0][0] + R[0][1] * adjT[0][1] + R[0][2] * adjT[0][2];
+  if (det == 0.0) return fail(SE3TN_E_ARG, "se3tn_render: singular pose");
+  const double l[3] = {0.0, 0.1, -0.9};
+  for (int r = 0; r < 3; ++r) a.light[r] = (float)((adjT[r][0] * l[0] + adjT[r][1] * l[1] + adjT[r][2] * l[2]) / det);
   HIPCHK(launch_raster(a, (hipStream_t)stream));
   return SE3TN_OK;
 }
@@ -1013,18 +1069,27 @@ int se3tn_render_frame(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], 
       return fail(SE3TN_E_STATE, "se3tn_render_frame: z-buffer too small for this frame inside a stream capture: call se3tn_reserve(ctx, H, W) first");
     if (int rc = reserve_zbuf(c, px)) return rc;
   }
+  if (H > 2048) return fail(SE3TN_E_ARG, "se3tn_render_frame: frames of more than 2048 rows are not supported");
   RasterArgs a{};
-  a.verts = m->verts; a.normals = m->normals; a.colors = m->colors; a.faces = m->faces; a.vwin = m->vwin;
-  a.zbuf = c->zbuf; a.big = m->big; a.rgb = rgb; a.depth = depth; a.V = m->V; a.F = m->F;
+  raster_common(a, c, m, rgb, depth);
   a.rw = W; a.rh = H; a.mode = 1;
   a.uv = m->uv; a.tex = m->tex; a.tw = m->tw; a.th = m->th; a.tlevels = m->tlevels;
   for (int i = 0; i < 16; ++i) a.tex_off[i] = m->tex_off[i];
   a.kd[0] = m->kd[0]; a.kd[1] = m->kd[1]; a.kd[2] = m->kd[2];
-  for (int i = 0; i < 12; ++i) a.M[i] = (float)ob_in_cam[i];
-  a.fx = (float)K[0]; a.fy = (float)K[4]; a.cx = (float)K[2]; a.cy = (float)K[5];
-  // IntrinsicsCamera at W x H: window x = u, row r = v  <=>  the Vispy-style window (left, top, right, bottom) =
-  // (0, 2 cy - H, W, 2 cy) in (u, cy - fy y / z) coordinates (raster.hip)
-  a.left = 0.f; a.right = (float)W; a.top = 2.f * a.cy - (float)H; a.bottom = 2.f * a.cy;
+  // pyrender's IntrinsicsCamera projection at W x H (GL clip space, y up) times cvcam_in_glcam . ob_in_cam, formed in float64 and
+  // uploaded as ONE float32 matrix; the vertex shader multiplies it with the position
+  const double n = R_NEAR_D, f = R_FAR_D;
+  double P[4][4] = {{2.0 * K[0] / W, 0.0, 1.0 - 2.0 * K[2] / W, 0.0},
+                    {0.0, 2.0 * K[4] / H, 2.0 * K[5] / H - 1.0, 0.0},
+                    {0.0, 0.0, (f + n) / (n - f), 2.0 * f * n / (n - f)},
+                    {0.0, 0.0, -1.0, 0.0}};
+  const double sgn[4] = {1.0, -1.0, -1.0, 1.0};
+  for (int r = 0; r < 4; ++r)
+    for (int q = 0; q < 4; ++q) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += P[r][k] * (sgn[k] * ob_in_cam[4 * k + q]);
+      a.PV[4 * r + q] = (float)acc;
+    }
   HIPCHK(launch_raster(a, (hipStream_t)stream));
   return SE3TN_OK;
 }

@@ -259,20 +259,24 @@ hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h,
                                       hipStream_t st);
 
 // rasteriser (raster.hip)
+constexpr double R_NEAR_D = 0.1, R_FAR_D = 2.0;   // vispy_renderer.py:139-140, offscreen_renderer.py znear / zfar
 struct RasterArgs {
   const float* verts;    // [V,3] object space
   const float* normals;  // [V,3]
   const float* colors;   // [V,3] in [0,1]
   const int* faces;      // [F,3]
-  float4* vwin;          // [V] scratch: window-space x, y, depth in [0,1], 1/w
-  unsigned long long* zbuf;  // [rw*rh] scratch
-  int* big;              // [1 + F] queue of triangles with large bounding boxes (big[0] = count) or nullptr
+  float4* vpost;         // [V] scratch: post-transform clip position (x, y, (z + w) / 2, w)
+  int4* vsnap;           // [V] scratch: window X, Y in 1 / 2^sub_bits pixel, bits of z / w, bits of 1 / w
+  unsigned long long* zbuf;  // [rw*rh] scratch: (sortable z << 32 | triangle)
+  int* big;              // [1 + F] queue of triangles with large bounding boxes (big[0] = count)
+  int* clipq;            // [1 + F] queue of triangles that cross the frustum
   uint8_t* rgb;          // out [rh,rw,3]
   uint16_t* depth;       // out [rh,rw] millimetres
-  float M[12];           // ob_in_cv_cam rows 0..2 (R | t)
-  float fx, fy, cx, cy;
-  float left, right, top, bottom;  // window in (X, Y) coordinates, Y = cy - fy y / z
+  float PV[16];          // the shader's proj * view (mode 1: u_pv), row-major
   float light[3];        // light_direction in object space
+  double dA, dB;         // mode 0: projection_matrix[2,2], [3,2] as vispy_renderer.py:163-164 reads them (float64)
+  int numpy_rule;        // SE3TN_OFFSET_RULE_*: the NumPy generation's scalar casting in vispy_renderer.py:165-169
+  int sub_bits;          // sub-pixel bits of the window coordinates (4 | 8)
   int V, F;
   int rw, rh;            // output resolution (176 x 176 for the Vispy-style window, the camera frame in pyrender mode)
   int mode;              // 0: VispyRenderer (Lambert shader, window crop)   1: pyrender (ambient only, full frame)

@@ -142,6 +142,14 @@ class Engine:
     def get_offset_rule(self):
         return "numpy2" if self.lib.se3tn_get_offset_rule(self._h) == _lib.OFFSET_RULE_NUMPY2 else "numpy1"
 
+    def set_raster_rule(self, sub_bits):
+        """Sub-pixel bits of the rasteriser's window coordinates: 4 (default: the software GL the goldens were rendered on, = the GL
+        minimum) or 8 (what desktop GPUs report for GL_SUBPIXEL_BITS).  include/se3tracknet.h: se3tn_set_raster_rule."""
+        check(self.lib.se3tn_set_raster_rule(self._h, int(sub_bits)), "se3tn_set_raster_rule")
+
+    def get_raster_rule(self):
+        return int(self.lib.se3tn_get_raster_rule(self._h))
+
     def set_winograd(self, min_batch, tile=0):
         """Batches of n >= min_batch run the 256/512-channel residual blocks as Winograd F(tile x tile,3x3) launch sequences (float32;
         tile 2 | 4 | 6 | _lib.WINOGRAD_TILE_6_4 = 6 for the 256-channel block + 4 for the heads | _lib.WINOGRAD_TILE_AUTO = 4 below 14

@@ -33,8 +33,10 @@ class HipRenderer:
         nrm = mesh.get("normals")
         if nrm is None:
             nrm = U.vertex_normals(v, f)
-        nrm = np.asarray(nrm, np.float64)
-        nrm = np.ascontiguousarray(nrm / np.linalg.norm(nrm, axis=1).reshape(-1, 1), np.float32)  # :126
+        nrm = np.asarray(nrm)
+        if nrm.dtype != np.float32:                                        # a float32 .ply property is normalised in float32 (:126)
+            nrm = nrm.astype(np.float64)
+        nrm = np.ascontiguousarray(nrm / np.linalg.norm(nrm, axis=1).reshape(-1, 1), np.float32)
         self.mesh = dict(vertices=v, faces=f, colors01=col, normals=nrm)
         h = C.c_void_p()
         check(engine.lib.se3tn_mesh_create(engine._h, v.ctypes.data, nrm.ctypes.data, col.ctypes.data, len(v),

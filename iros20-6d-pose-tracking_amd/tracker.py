@@ -1,9 +1,11 @@
 """Drop-in for the reference's ``predict.Tracker`` (predict.py:127-296): same constructor
 arguments, ``on_track`` signature / return value and the attributes callers read (``K``,
 ``object_cloud``, ``object_width``, ``dataset`` with processData / processPredict, callable ``model``).  The arithmetic of on_track runs on the GPU
-through the C ABI: se3tn_preprocess -> se3tn_infer (network + pose update); only compute_bbox is
-host float64 exactly as the reference.  Rendering (predict.py:193-215) is out of the kernel scope:
-a renderer object is injected (``renderer.render(ob_in_cam, K, window) -> rgb u8, depth u16``)."""
+through the C ABI: se3tn_render (image A, predict.py:193-215) -> se3tn_preprocess -> se3tn_infer (network + pose update); only
+compute_bbox is host float64 exactly as the reference.  Given a model file the constructor builds the HIP rasteriser itself
+(``HipRenderer``: byte-identical to the reference's VispyRenderer on the GL implementation the goldens were rendered on); a
+renderer object with the reference's protocol can be injected instead (``renderer.render(ob_in_cam, K, window) -> rgb u8,
+depth u16`` or the full-frame ``render([ob_in_cam])`` of offscreen_renderer.Renderer)."""
 import numpy as np
 import torch
 

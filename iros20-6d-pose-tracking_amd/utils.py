@@ -72,7 +72,8 @@ def _read_ply(path):
             if not has_list:
                 if fmt == "ascii":
                     arr = np.loadtxt(f, max_rows=n, ndmin=2) if n else np.zeros((0, len(props)))
-                    data[el["name"]] = {nm: arr[:, i] for i, nm in enumerate(names)}
+                    # every property in its DECLARED type, as plyfile returns it (the reference normalises `float` normals in float32)
+                    data[el["name"]] = {nm: arr[:, i].astype(_PLY_TYPES[p_[0]]) for i, (nm, p_) in enumerate(zip(names, props))}
                 else:
                     dt = np.dtype([(nm, bo + _PLY_TYPES[p_[0]]) for nm, p_ in zip(names, props)])
                     rec = np.frombuffer(f.read(dt.itemsize * n), dtype=dt, count=n)
@@ -91,7 +92,7 @@ def _read_ply(path):
                         ks = {len(v) for v in vals}
                         out[p_[-1]] = np.asarray(vals, np.int64).reshape(n, -1) if len(ks) == 1 else vals
                     else:
-                        out[p_[-1]] = np.array([float(r[col[i]]) for i, r in enumerate(rows)])
+                        out[p_[-1]] = np.array([float(r[col[i]]) for i, r in enumerate(rows)]).astype(_PLY_TYPES[p_[0]])
                         col = [c + 1 for c in col]
                 data[el["name"]] = out
                 continue
@@ -175,8 +176,11 @@ def load_ply_mesh(path):
         out["colors"] = np.stack([v["red"], v["green"], v["blue"]], 1)
     else:
         out["colors"] = np.full((len(out["vertices"]), 3), 255.0)
-    out["normals"] = np.stack([v["nx"], v["ny"], v["nz"]], 1) if "nx" in v else None
-    if out["normals"] is not None and not np.all(np.linalg.norm(out["normals"], axis=1) > 0):
+    # normals in the file's declared type: vispy_renderer.py:126 normalises them in whatever dtype plyfile returned (float32 for
+    # `property float`), and that arithmetic reaches image A
+    raw = data["vertex"]
+    out["normals"] = np.stack([np.asarray(raw[k]) for k in ("nx", "ny", "nz")], 1) if "nx" in v else None
+    if out["normals"] is not None and not np.all(np.linalg.norm(out["normals"].astype(np.float64), axis=1) > 0):
         out["normals"] = None
     return out
 

@@ -5,7 +5,6 @@ every golden file also stores fingerprints of its inputs to detect generator dri
 import hashlib
 
 import numpy as np
-import torch
 
 # dataset_info.yml:4-7
 K_YCB = np.array([[1066.778, 0.0, 312.9869], [0.0, 1067.487, 241.3109], [0.0, 0.0, 1.0]])
@@ -89,6 +88,7 @@ def pose(seed, t=(0.05, -0.02, 0.8)):
 
 
 def net_inputs(seed, n, scale=1.0, res=176):
+    import torch                                   # lazily: the renderer fixtures also run under an interpreter without torch
     g = torch.Generator().manual_seed(seed)
     A = torch.randn((n, 4, res, res), generator=g) * scale
     B = torch.randn((n, 4, res, res), generator=g) * scale

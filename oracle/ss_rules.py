@@ -13,7 +13,8 @@ below was fitted as a hypothesis and then CONFIRMED BIT FOR BIT against the live
               (GL_SUBPIXEL_BITS = 4) with the pixel centres on multiples of 16; round half to even;  Z = z' rhw
   coverage    exact integers on (X, Y): rows ceil(Ymin / 16) <= y < ceil(Ymax / 16), columns ceil(xl(y)) <= x < ceil(xr(y))
               == edge functions with E > 0, or E == 0 on edges with dy < 0 or (dy == 0 and dx > 0) (orientation made positive)
-  rotation    the triangle's vertices are rotated so that v0 has the largest clip w (ties: first v1, then v2)
+  rotation    the triangle's vertices are rotated so that v0 has the largest clip w (w1 == wmax: rotate left; ORIGINAL
+              w2 == wmax: rotate right -- with w1 == w2 == wmax the two cancel)
   depth       z = (C + (y - Y0/16) B) + (x - X0/16) A with A = 16 (y2 z1 - y1 z2) D, B = 16 (x1 z2 - x2 z1) D, D = 1 / (x1 y2 - x2 y1)
               on the integer deltas converted to float; evaluated per 2 x 2 quad as (float(xq) + (xoff - X0/16)); LESS, in draw order
   varyings    plane equations of attribute / w from M (below), w interpolated as 1 / w, rcp = 1 / w then one Newton step
@@ -52,15 +53,16 @@ def clip_positions(verts, PV):
     return acc
 
 
-def project(clip, W, H):
-    """post-transform position, snapped window coordinates, depth and 1/w per vertex"""
+def project(clip, W, H, sub_bits=4):
+    """post-transform position, snapped window coordinates (1 / 2^sub_bits pixel), depth and 1/w per vertex"""
+    sub = 1 << sub_bits
     x, y, z, w = [np.ascontiguousarray(clip[:, i], f32) for i in range(4)]
     zc = ((z + w).astype(f32) * f32(0.5)).astype(f32)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         wsafe = np.where(w == 0, f32(1), w).astype(f32)
         rhw = (f32(1) / wsafe).astype(f32)
-        Wx16, Hx16 = f32(W * 0.5 * 16), f32(H * 0.5 * 16)
-        X0x16, Y0x16 = f32(W * 0.5 * 16 - 8), f32(H * 0.5 * 16 - 8)
+        Wx16, Hx16 = f32(W * 0.5 * sub), f32(H * 0.5 * sub)
+        X0x16, Y0x16 = f32(W * 0.5 * sub - sub / 2), f32(H * 0.5 * sub - sub / 2)
         Xf = (X0x16 + ((x * rhw).astype(f32) * Wx16).astype(f32)).astype(f32)
         Yf = (Y0x16 + ((y * rhw).astype(f32) * Hx16).astype(f32)).astype(f32)
         X = np.where(np.abs(Xf) < 2.0 ** 30, np.rint(Xf), -2.0 ** 31).astype(np.int64)
@@ -68,7 +70,7 @@ def project(clip, W, H):
         Z = (zc * rhw).astype(f32)
     flags = ((x > w) * 1) | ((y > w) * 2) | ((zc > w) * 4) | ((x < -w) * 8) | ((y < -w) * 16) | ((zc < 0) * 32)
     post = np.stack([x, y, zc, w], 1)
-    return dict(post=post, X=X, Y=Y, Z=Z, rhw=rhw, w=w, flags=flags.astype(np.int32))
+    return dict(post=post, X=X, Y=Y, Z=Z, rhw=rhw, w=w, flags=flags.astype(np.int32), sub_bits=sub_bits)
 
 
 CLIP_RIGHT, CLIP_TOP, CLIP_FAR, CLIP_LEFT, CLIP_BOTTOM, CLIP_NEAR = 1, 2, 4, 8, 16, 32
@@ -111,10 +113,11 @@ def clip_polygon(poly, flags_or):
     return poly
 
 
-def _snap_polygon(poly, W, H):
+def _snap_polygon(poly, W, H, sub_bits=4):
     Xs, Ys = [], []
-    Wx16, Hx16 = f32(W * 0.5 * 16), f32(H * 0.5 * 16)
-    X0x16, Y0x16 = f32(W * 0.5 * 16 - 8), f32(H * 0.5 * 16 - 8)
+    sub = 1 << sub_bits
+    Wx16, Hx16 = f32(W * 0.5 * sub), f32(H * 0.5 * sub)
+    X0x16, Y0x16 = f32(W * 0.5 * sub - sub / 2), f32(H * 0.5 * sub - sub / 2)
     for v in poly:
         w = f32(v[3])
         rhw = f32(1) / w if w != 0 else f32(1)
@@ -128,10 +131,11 @@ def _cdiv(a, b):            # C division: truncation towards zero
     return q if (a >= 0) == (b > 0) else -q
 
 
-def outline(Xs, Ys, d, W, H):
+def outline(Xs, Ys, d, W, H, sub_bits=4):
     """The span tables an n-gon's edges leave behind, walked in the implementation's order.  d = 1 if the snapped TRIANGLE's
     area (y2-y0) x1 + (y1-y2) x0 + (y0-y1) x2 (sign-corrected by the w signs) is < 0, else 0.  Returns (left, right, y0, y1)."""
     n = len(Xs)
+    sb, sm = sub_bits, (1 << sub_bits) - 1
     left = np.zeros(H + 1, np.int64)
     right = np.zeros(H + 1, np.int64)
     Xq, Yq = list(Xs) + [Xs[0]], list(Ys) + [Ys[0]]
@@ -141,15 +145,15 @@ def outline(Xs, Ys, d, W, H):
             continue
         swap = Yb < Ya
         X1, Y1, X2, Y2 = (Xb, Yb, Xa, Ya) if swap else (Xa, Ya, Xb, Yb)
-        y1 = max((Y1 + 15) >> 4, 0)
-        y2 = min((Y2 + 15) >> 4, H)
+        y1 = max((Y1 + sm) >> sb, 0)
+        y2 = min((Y2 + sm) >> sb, H)
         if y1 >= y2:
             continue
         table = right if swap else left
         DX, DY = X2 - X1, Y2 - Y1
-        FDX, FDY = DX << 4, DY << 4
-        Xn = DX * ((y1 << 4) - Y1) + (X1 & 15) * DY
-        x = (X1 >> 4) + _cdiv(Xn, FDY)
+        FDX, FDY = DX << sb, DY << sb
+        Xn = DX * ((y1 << sb) - Y1) + (X1 & sm) * DY
+        x = (X1 >> sb) + _cdiv(Xn, FDY)
         dd = Xn - _cdiv(Xn, FDY) * FDY
         if dd > 0:
             x += 1
@@ -166,17 +170,20 @@ def outline(Xs, Ys, d, W, H):
             if dd > 0:
                 dd -= FDY
                 x += 1
-    ymin = max((min(Ys) + 15) >> 4, 0)
-    ymax = min((max(Ys) + 15) >> 4, H)
+    ymin = max((min(Ys) + sm) >> sb, 0)
+    ymax = min((max(Ys) + sm) >> sb, H)
     return left, right, ymin, ymax
 
 
 def _rotate_max_w(idx, w):
+    """v0 <- the vertex with the largest clip w.  Both conditions are evaluated on the ORIGINAL order (w1 == wmax rotates left,
+    then w2 == wmax rotates right): with w1 == w2 == wmax the two rotations cancel and v0 stays."""
+    o = list(idx)
     i = list(idx)
-    wmax = max(w[i[0]], w[i[1]], w[i[2]])
-    if wmax == w[i[1]]:
+    wmax = max(w[o[0]], w[o[1]], w[o[2]])
+    if wmax == w[o[1]]:
         i = [i[1], i[2], i[0]]
-    if wmax == w[i[2]]:
+    if wmax == w[o[2]]:
         i = [i[2], i[0], i[1]]
     return i
 
@@ -190,6 +197,8 @@ def setup_triangle(pv, tri, W, H):
     X, Y, Z, w, rhw, flags, post = pv["X"], pv["Y"], pv["Z"], pv["w"], pv["rhw"], pv["flags"], pv["post"]
     s = Setup()
     s.ok = False
+    sb = pv.get("sub_bits", 4)
+    sub = 1 << sb
     i0, i1, i2 = [int(t) for t in tri]
     if flags[i0] & flags[i1] & flags[i2]:
         return s
@@ -207,10 +216,10 @@ def setup_triangle(pv, tri, W, H):
         poly = clip_polygon([post[i0].copy(), post[i1].copy(), post[i2].copy()], flags_or)
         if len(poly) < 3:
             return s
-        Xs, Ys = _snap_polygon(poly, W, H)
+        Xs, Ys = _snap_polygon(poly, W, H, sb)
     else:
         Xs, Ys = [int(X[i0]), int(X[i1]), int(X[i2])], [int(Y[i0]), int(Y[i1]), int(Y[i2])]
-    left, right, ymin, ymax = outline(Xs, Ys, d, W, H)
+    left, right, ymin, ymax = outline(Xs, Ys, d, W, H, sb)
     while ymin < ymax and left[ymin] == right[ymin]:
         ymin += 1
     while ymax > ymin and left[ymax - 1] == right[ymax - 1]:
@@ -225,10 +234,10 @@ def setup_triangle(pv, tri, W, H):
     Y0, Y1, Y2 = [int(Y[k]) for k in r]
     w0, w1, w2 = [f32(w[k]) for k in r]
     rhw0 = f32(rhw[r[0]])
-    s.dx, s.dy = f32(f32(X0) * f32(1.0 / 16.0)), f32(f32(Y0) * f32(1.0 / 16.0))
+    s.dx, s.dy = f32(f32(X0) * f32(1.0 / sub)), f32(f32(Y0) * f32(1.0 / sub))
     X1 -= X0; Y1 -= Y0; X2 -= X0; Y2 -= Y0
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
-        sc = f32(1.0 / 16.0)
+        sc = f32(1.0 / sub)
         px1, py1 = f32(f32(w1 * sc) * f32(X1)), f32(f32(w1 * sc) * f32(Y1))
         px2, py2 = f32(f32(w2 * sc) * f32(X2)), f32(f32(w2 * sc) * f32(Y2))
         a = f32(f32(px1 * py2) - f32(px2 * py1))
@@ -248,8 +257,8 @@ def setup_triangle(pv, tri, W, H):
         z1, z2 = f32(z1 - z0), f32(z2 - z0)
         fx1, fy1, fx2, fy2 = f32(X1), f32(Y1), f32(X2), f32(Y2)
         D = f32(f32(1) / f32(f32(fx1 * fy2) - f32(fx2 * fy1)))
-        s.zA = f32(f32(f32(f32(fy2 * z1) - f32(fy1 * z2)) * D) * f32(16))
-        s.zB = f32(f32(f32(f32(fx1 * z2) - f32(fx2 * z1)) * D) * f32(16))
+        s.zA = f32(f32(f32(f32(fy2 * z1) - f32(fy1 * z2)) * D) * f32(sub))
+        s.zB = f32(f32(f32(f32(fx1 * z2) - f32(fx2 * z1)) * D) * f32(sub))
         s.zC = f32(f32(z0 * f32(1)) + f32(0))
     s.ok = True
     return s
@@ -351,14 +360,14 @@ def shade_vispy(pos, nrm, col, light):
     return np.minimum(np.maximum(c, f32(0)), f32(1))
 
 
-def render_vispy(vertices, normals, colors01, faces, ob2cam, K, window, size=176, return_float=False):
+def render_vispy(vertices, normals, colors01, faces, ob2cam, K, window, size=176, return_float=False, numpy_rule="numpy2", sub_bits=4):
     """The reference's VispyRenderer.render_image on this model: rgb uint8 [size,size,3], depth uint16 [size,size]
     (rows as the reference returns them)."""
     W = H = size
     P, V, light, (pA, pB) = vispy_uniforms(ob2cam, K, window)
     PV = _mat_mul_cols(P, V)
     v32 = np.asarray(vertices, np.float32)
-    pv = project(clip_positions(v32, PV), W, H)
+    pv = project(clip_positions(v32, PV), W, H, sub_bits)
     zbuf, owner, setups = rasterize(pv, faces, W, H)
     colf = np.zeros((H, W, 3), f32)
     n32, c32 = np.asarray(normals, np.float32), np.asarray(colors01, np.float32)
@@ -372,14 +381,76 @@ def render_vispy(vertices, normals, colors01, faces, ob2cam, K, window, size=176
         colf[ys, xs] = shade_vispy(a[:, 0:3], a[:, 3:6], a[:, 6:9], light)
     rgb = unorm8(colf)
     rgb[owner < 0] = 0
-    # vispy_renderer.py:163-169 (numpy float32 array with python-float scalars, NumPy >= 2 keeps float32)
-    A_, B_ = pA, pB
-    depth = zbuf
-    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
-        distance = B_ / (depth * -2.0 + 1.0 - A_) * -1
-        distance = np.asarray(distance)
-        distance[distance >= B_ / (A_ + 1)] = 0
-        d16 = (distance * 1000).astype(np.uint16)
+    d16 = depth_mm(zbuf, pA, pB, numpy_rule)
     if return_float:
         return rgb, d16, colf, zbuf, owner
     return rgb, d16
+
+
+def depth_mm(zbuf, A, B, numpy_rule="numpy2"):
+    """vispy_renderer.py:163-169: float32 depth buffer -> uint16 millimetres.  A, B are float64 scalars there.
+    'numpy2': `depth * -2.0 + 1.0` stays float32, `- A` promotes to float64, everything after is float64 (NEP 50);
+    'numpy1': value-based casting -- the scalars are cast to float32, every operation is a float32 operation."""
+    z = np.asarray(zbuf, f32)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        if numpy_rule == "numpy2":
+            t = ((z * f32(-2.0)).astype(f32) + f32(1.0)).astype(f32).astype(np.float64)
+            distance = np.float64(B) / (t - np.float64(A)) * -1.0
+            distance[distance >= np.float64(B) / (np.float64(A) + 1)] = 0
+            return (distance * 1000).astype(np.uint16)
+        assert numpy_rule == "numpy1", numpy_rule
+        t = (((z * f32(-2.0)).astype(f32) + f32(1.0)).astype(f32) - f32(A)).astype(f32)
+        distance = ((f32(B) / t).astype(f32) * f32(-1)).astype(f32)
+        distance[distance >= f32(np.float64(B) / (np.float64(A) + 1))] = 0
+        return (distance * f32(1000)).astype(f32).astype(np.uint16)
+
+
+def render_frame(vertices, colors01, faces, ob2cam, K, W, H, uv=None, texture=None, kd=(1.0, 1.0, 1.0), near=NEAR, far=FAR):
+    """The second renderer's GL work (oracle/swiftshader_gl.py: render_frame_gl, this repo's statement of pyrender's scene) on this
+    model: coverage, depth and vertex colours by the rules above (exact); the texture FILTER is plain float32 arithmetic
+    (raster_oracle's bilinear / trilinear with the level of detail from the 2 x 2 quad's differences) -- the implementation
+    filters in 16-bit fixed point, so textured colours agree to a few / 255 only.  rgb uint8 [H,W,3], depth uint16 [H,W]."""
+    from . import raster_oracle as R
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    P = np.zeros((4, 4))
+    P[0, 0] = 2.0 * fx / W; P[1, 1] = 2.0 * fy / H
+    P[0, 2] = 1.0 - 2.0 * cx / W; P[1, 2] = 2.0 * cy / H - 1.0
+    P[2, 2] = (far + near) / (near - far); P[2, 3] = 2 * far * near / (near - far); P[3, 2] = -1.0
+    V = np.diag([1.0, -1.0, -1.0, 1.0]).dot(np.asarray(ob2cam, np.float64))
+    PV = (P @ V).astype(np.float32)
+    v32 = np.asarray(vertices, np.float32)
+    pv = project(clip_positions(v32, PV), W, H)
+    zbuf, owner, setups = rasterize(pv, faces, W, H)
+    colf = np.zeros((H, W, 3), f32)
+    kd = np.asarray(kd, f32)
+    levels = R.mip_pyramid(texture) if texture is not None else None
+    for t, s in setups.items():
+        ys, xs = np.nonzero(owner == t)
+        if len(ys) == 0:
+            continue
+        if levels is None:
+            base = interpolate(s, np.asarray(colors01, f32)[s.idx], xs, ys)
+        else:
+            uvt = np.asarray(uv, f32)[s.idx]
+            th, tw = levels[0].shape[:2]
+            c = interpolate(s, uvt, xs, ys)
+            xq, yq = xs // 2 * 2, ys // 2 * 2
+            q0, q1, q2 = interpolate(s, uvt, xq, yq), interpolate(s, uvt, xq + 1, yq), interpolate(s, uvt, xq, yq + 1)
+            base = np.zeros((len(xs), 3), f32)
+            for k in range(len(xs)):
+                dx = ((q1[k] - q0[k]).astype(f32) * np.array([tw, th], f32)).astype(f32)
+                dy = ((q2[k] - q0[k]).astype(f32) * np.array([tw, th], f32)).astype(f32)
+                rho = max(float(np.sqrt(f32((dx * dx).astype(f32).sum(dtype=f32)))), float(np.sqrt(f32((dy * dy).astype(f32).sum(dtype=f32)))))
+                lod = min(max(np.log2(max(rho, 1e-8)), 0.0), len(levels) - 1)
+                l0 = int(np.floor(lod)); l1 = min(l0 + 1, len(levels) - 1); fl = f32(lod - l0)
+                c0 = R._bilinear(levels[l0], c[k, 0], c[k, 1]); c1 = R._bilinear(levels[l1], c[k, 0], c[k, 1])
+                base[k] = (c0 + fl * (c1 - c0)) / f32(255.0)
+        colf[ys, xs] = np.minimum(np.maximum((base * kd[None, :]).astype(f32), f32(0)), f32(1))
+    rgb = unorm8(colf)
+    rgb[owner < 0] = 0
+    rgb, z, hit = rgb[::-1].copy(), zbuf[::-1].copy(), (owner >= 0)[::-1].copy()       # rows flipped on read-back
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z_ndc = (z * f32(2.0)).astype(f32) - f32(1.0)
+        depth = (f32(2.0 * near * far) / (f32(far + near) - (z_ndc * f32(far - near)).astype(f32)).astype(f32)).astype(f32)
+    depth[~hit] = 0
+    return rgb, (depth * f32(1000)).astype(f32).astype(np.uint16)

@@ -1,13 +1,14 @@
-"""The rendered image A against a REAL OpenGL implementation (VERDICT r2 missing #1, rows a3 / f1).
+"""The rendered image A against a REAL OpenGL implementation (rows a3 / f1).
 tests/golden/gl_swiftshader.npz was produced by oracle/make_gl_golden.py: the UNMODIFIED reference class VispyRenderer
 (vispy_renderer.py:47-178), driven as Tracker.render_window drives it (predict.py:193-208), executing on Google SwiftShader's
 OpenGL ES 3.0 (Khronos-conformant software GL, shipped in the kaleido wheel of this image) through the thin vispy / PyOpenGL
-stand-ins of oracle/swiftshader_gl.py.  Fill rule, clipping, perspective-correct interpolation, depth test, float -> unorm8
-conversion and read-back row order are GL's own here.  Compared: the numpy restatement of the pipeline (oracle/raster_oracle.py,
-CPU) and the HIP rasteriser (GPU).  Expected differences and their cause: SwiftShader snaps vertices to 1/16 pixel
-(GL_SUBPIXEL_BITS = 4; the GL minimum), neither the oracle nor the HIP kernels snap -> a handful of silhouette pixels change
-owner, and on meshes with pixel-sized triangles (steep colour gradients between random vertex colours) interior colours move
-by 1-2 / 255."""
+stand-ins of oracle/swiftshader_gl.py; gl_swiftshader_numpy1.npz is the same class under NumPy 1.26 (the generation the
+reference pins; only the depth read-back arithmetic differs).  Fill rule, sub-pixel snapping, clipping, interpolation
+arithmetic, depth test, float -> unorm8 conversion and read-back row order are GL's own there.
+Round 5: BYTE EQUALITY.  oracle/ss_rules.py states that implementation's arithmetic operation by operation (each rule confirmed
+bit for bit against the live library: tests/test_ss_rules.py) and csrc/raster.hip executes the same statement on the GPU: both
+must reproduce every golden image exactly -- 0 coverage mismatches, identical depth, identical rgb -- from the .ply file the
+reference loaded."""
 import os
 
 import numpy as np
@@ -24,20 +25,37 @@ def golden(golden_dir):
     return np.load(os.path.join(golden_dir, "gl_swiftshader.npz"))
 
 
-def _compare(rgb, depth, want_rgb, want_d, tiny_triangles):
+@pytest.fixture(scope="module")
+def golden1(golden_dir):
+    return np.load(os.path.join(golden_dir, "gl_swiftshader_numpy1.npz"))
+
+
+def _compare(rgb, depth, want_rgb, want_d):
+    """image A is defined by the golden: every byte"""
     assert rgb.shape == want_rgb.shape == (176, 176, 3) and depth.dtype == want_d.dtype == np.uint16
     cov, wcov = depth > 0, want_d > 0
-    assert (cov != wcov).sum() <= 12, (cov != wcov).sum()                      # of 30,976 pixels: silhouette pixels, sub-pixel snapping
-    both = cov & wcov
-    assert both.sum() > 10000
-    dd = np.abs(depth[both].astype(int) - want_d[both].astype(int))
-    assert dd.max() <= 1 and (dd > 0).mean() < 0.03                            # uint16 mm truncation flips
-    inner = ndimage.binary_erosion(both, iterations=2)
-    d = np.abs(rgb.astype(int) - want_rgb.astype(int)).max(2)
-    assert d[inner].max() <= (6 if tiny_triangles else 3), d[inner].max()
-    assert np.percentile(d[inner], 99) <= 2 and (d[inner] == 0).mean() > (0.40 if tiny_triangles else 0.60)
-    assert d[both & ~inner].max() <= 40                                        # rim: a different (randomly coloured) triangle owns the pixel
-    assert (rgb[~cov] == 0).all() and (want_rgb[~wcov] == 0).all()            # background exactly 0 in both (maskA = depthA > 100)
+    assert (cov != wcov).sum() == 0, "coverage: %d pixels differ" % (cov != wcov).sum()
+    assert np.array_equal(depth, want_d), "depth: %d pixels differ (max %d mm)" % (
+        (depth != want_d).sum(), np.abs(depth.astype(int) - want_d.astype(int)).max())
+    assert np.array_equal(rgb, want_rgb), "rgb: %d pixels differ (max %d)" % (
+        (rgb != want_rgb).any(2).sum(), np.abs(rgb.astype(int) - want_rgb.astype(int)).max())
+    assert wcov.sum() > 10000 and (want_rgb[~wcov] == 0).all()
+
+
+def _ply_mesh(tmp_path, seed, subdiv):
+    """The .ply the golden run wrote (make_gl_golden.write_ply), and the arrays the reference class makes of it
+    (vispy_renderer.py:113-132: `property float` columns are float32, normals normalised in that type, colours / 255.0)."""
+    from oracle import ply_io
+    from oracle.make_gl_golden import write_ply
+    path = os.path.join(str(tmp_path), "m%d.ply" % seed)
+    write_ply(path, Fx.icosphere(subdiv, 0.05, seed))
+    v = ply_io.read_ply(path)["vertex"]
+    vert = np.stack([v["x"], v["y"], v["z"]], -1)
+    nrm = np.stack([v["nx"], v["ny"], v["nz"]], -1)
+    assert vert.dtype == nrm.dtype == np.float32
+    nrm = nrm / np.linalg.norm(nrm, axis=1).reshape(-1, 1)
+    col = (np.stack([v["red"], v["green"], v["blue"]], -1) / 255.0).astype(np.float32)
+    return path, vert, nrm.astype(np.float32), col
 
 
 def test_golden_facts(golden):
@@ -48,15 +66,23 @@ def test_golden_facts(golden):
         assert z - 55 <= d[d > 0].min() <= z - 40 and d.max() <= z + 15          # a 50 mm sphere: nearest point z - 50 mm, off-axis rim a little beyond z
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if c[1] <= 2], ids=lambda c: "seed%d" % c[0])
-def test_raster_oracle_vs_real_gl(golden, case):
-    from oracle import raster_oracle as R
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d" % c[0])
+def test_gl_rules_reproduce_the_golden_bytes(golden, golden1, case, tmp_path):
+    from oracle import ss_rules as S
     seed, subdiv, t = case
-    m = Fx.icosphere(subdiv, 0.05, seed)
+    _, vert, nrm, col = _ply_mesh(tmp_path, seed, subdiv)
+    faces = Fx.icosphere(subdiv, 0.05, seed)["faces"]
     win = tuple(int(x) for x in golden["window_%d" % seed])
-    rgb, depth = R.render(m["vertices"], m["normals"].astype(np.float32), (m["colors"] / 255.0).astype(np.float32), m["faces"],
-                          Fx.pose(seed, t), Fx.K_YCB, win)
-    _compare(rgb, depth, golden["rgb_%d" % seed], golden["depth_%d" % seed], tiny_triangles=False)
+    rgb, depth, _, zbuf, _ = S.render_vispy(vert, nrm, col, faces, Fx.pose(seed, t), Fx.K_YCB, win, return_float=True)
+    _compare(rgb, depth, golden["rgb_%d" % seed], golden["depth_%d" % seed])
+    assert np.array_equal(zbuf.view(np.int32), golden1["zbuf_%d" % seed].view(np.int32))      # the raw depth buffer, bit for bit
+    rgb1, depth1 = S.render_vispy(vert, nrm, col, faces, Fx.pose(seed, t), Fx.K_YCB, win, numpy_rule="numpy1")
+    _compare(rgb1, depth1, golden["rgb_%d" % seed], golden1["depth_%d" % seed])
+
+
+def test_numpy_generations_differ_in_the_depth_read_back(golden, golden1):
+    n = sum(int((golden["depth_%d" % c[0]] != golden1["depth_%d" % c[0]]).sum()) for c in CASES)
+    assert 1 <= n <= 60 and str(golden1["numpy_version"]).startswith("1.")          # a handful of pixels land on another millimetre
 
 
 def test_golden_is_what_swiftshader_renders_today(golden, tmp_path):
@@ -80,39 +106,58 @@ def test_golden_is_what_swiftshader_renders_today(golden, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d" % c[0])
-def test_hip_rasteriser_vs_real_gl(golden, case):
+def test_hip_rasteriser_vs_real_gl(golden, golden1, case, tmp_path):
     import se3tracknet_amd as se3
     seed, subdiv, t = case
     eng = se3.Engine(0, 1)
-    ren = se3.HipRenderer(eng, Fx.icosphere(subdiv, 0.05, seed))
+    path, _, _, _ = _ply_mesh(tmp_path, seed, subdiv)
+    ren = se3.HipRenderer(eng, path)                                                  # the file the reference loaded
     P = Fx.pose(seed, t)
     win = se3.HipRenderer.gl_window(P, Fx.K_YCB, OBJECT_WIDTH)
     assert tuple(int(x) for x in golden["window_%d" % seed]) == tuple(win)          # the reference's own compute_bbox window
+    assert eng.get_offset_rule() == "numpy1" and eng.get_raster_rule() == 4
     rgb, depth = ren.render(P, Fx.K_YCB, win)
-    _compare(rgb, depth, golden["rgb_%d" % seed], golden["depth_%d" % seed], tiny_triangles=subdiv >= 4)
+    _compare(rgb, depth, golden["rgb_%d" % seed], golden1["depth_%d" % seed])       # default: the reference's pinned NumPy generation
+    eng.set_offset_rule("numpy2")
+    rgb, depth = ren.render(P, Fx.K_YCB, win)
+    _compare(rgb, depth, golden["rgb_%d" % seed], golden["depth_%d" % seed])
+
+
+@pytest.mark.gpu
+def test_hip_rasteriser_with_8_subpixel_bits_equals_the_rules(tmp_path):
+    """se3tn_set_raster_rule(8): the same statement with window coordinates in 1/256 pixel (what desktop GPUs report)."""
+    import se3tracknet_amd as se3
+    from oracle import ss_rules as S
+    seed, subdiv, t = CASES[1]
+    eng = se3.Engine(0, 1)
+    path, vert, nrm, col = _ply_mesh(tmp_path, seed, subdiv)
+    eng.set_raster_rule(8)
+    P = Fx.pose(seed, t)
+    win = se3.HipRenderer.gl_window(P, Fx.K_YCB, OBJECT_WIDTH)
+    rgb, depth = se3.HipRenderer(eng, path).render(P, Fx.K_YCB, win)
+    want_rgb, want_d = S.render_vispy(vert, nrm, col, Fx.icosphere(subdiv, 0.05, seed)["faces"], P, Fx.K_YCB, win, numpy_rule="numpy1", sub_bits=8)
+    assert np.array_equal(rgb, want_rgb) and np.array_equal(depth, want_d)
+    rgb4, d4 = S.render_vispy(vert, nrm, col, Fx.icosphere(subdiv, 0.05, seed)["faces"], P, Fx.K_YCB, win, numpy_rule="numpy1")
+    assert 0 < ((d4 > 0) != (want_d > 0)).sum() <= 12                                # a handful of silhouette pixels change owner
 
 
 # ---- second renderer (pyrender route, full camera frame): GL's sampling / fill rules; pyrender's scene set-up is this repo's reading ------
 def _compare_frame(rgb, depth, want_rgb, want_d, textured):
     assert rgb.shape == want_rgb.shape and depth.shape == want_d.shape
     cov, wcov = depth > 0, want_d > 0
-    assert (cov != wcov).sum() <= 6
-    both = cov & wcov
-    dd = np.abs(depth[both].astype(int) - want_d[both].astype(int))
-    assert dd.max() <= 2 and (dd > 1).mean() < 0.005
-    inner = ndimage.binary_erosion(both, iterations=2)
+    assert (cov != wcov).sum() == 0 and np.array_equal(depth, want_d)              # coverage and depth: every pixel
     d = np.abs(rgb.astype(int) - want_rgb.astype(int)).max(2)
-    if textured:   # the texture carries 5 % white speckles: single texels dominate a few pixels' level-of-detail blend
-        assert np.percentile(d[inner], 99) <= 6 and np.median(d[inner]) <= 1 and (d[inner] > 8).mean() < 0.01, np.percentile(d[inner], 99)
+    if textured:   # the texture FILTER is float32 arithmetic in this repo, 16-bit fixed point in the GL implementation
+        assert d.max() <= 4 and np.percentile(d[wcov], 99) <= 2 and np.median(d[wcov]) <= 1, (d.max(), np.percentile(d[wcov], 99))
     else:
-        assert d[inner].max() <= 3
+        assert np.array_equal(rgb, want_rgb)
     assert (rgb[~cov] == 0).all() and (want_rgb[~wcov] == 0).all()
 
 
 @pytest.mark.parametrize("i", [0, 1])
 @pytest.mark.parametrize("textured", [True, False])
 def test_frame_oracle_vs_real_gl(golden, i, textured):
-    from oracle import raster_oracle as R
+    from oracle import ss_rules as R
     from oracle.make_gl_golden import FRAME_HW, FRAME_K, FRAME_KD_VERTEX, FRAME_POSES
     H, W = FRAME_HW
     ms = Fx.textured_sphere(2)
@@ -151,8 +196,9 @@ def test_hip_full_frame_renderer_vs_real_gl(golden, i):
 @pytest.mark.gpu
 def test_on_track_with_real_gl_image_A_vs_hip_image_A(golden):
     """End to end: Tracker.on_track with image A from the HIP rasteriser vs the SAME call with image A = what the reference's
-    VispyRenderer rendered on real GL (injected through the renderer protocol).  The rasterisers differ in a handful of
-    silhouette pixels and by 1-2 / 255 inside; this bounds what that does to the network output and the pose."""
+    VispyRenderer rendered on real GL (injected through the renderer protocol).  Meshes here are passed as arrays (float64
+    normals, normalised in float64) while the golden's came through a float32 .ply: interior colours may differ by 1 / 255 on
+    a few pixels; coverage and depth are identical.  This bounds what that does to the network output and the pose."""
     import se3tracknet_amd as se3
     from oracle import se3_oracle as O
     sd = O.make_state_dict(0, head_gain=0.002)
@@ -176,4 +222,4 @@ def test_on_track_with_real_gl_image_A_vs_hip_image_A(golden):
         worst_net = max(worst_net, float(np.abs(out_hip - out_gl).max()))
         worst_pose = max(worst_pose, float(np.abs(pose_hip - pose_gl).max()))
     print("image A from real GL vs from the HIP rasteriser: max |d(trans, rot)| = %.2e, max |d pose| = %.2e" % (worst_net, worst_pose))
-    assert worst_net < 5e-3 and worst_pose < 2e-4
+    assert worst_net < 1e-4 and worst_pose < 1e-5                                   # the north-star tolerances (round 4: 5e-3 / 2e-4)

@@ -1,11 +1,14 @@
-"""Rasteriser: the HIP kernels against the CPU restatement of the reference's
-OpenGL pipeline (oracle/raster_oracle.py; parity with a real GL driver is unpinned), plus properties."""
+"""Rasteriser: the HIP kernels against the CPU statement of the GL implementation the goldens were
+rendered on (oracle/ss_rules.py, confirmed bit for bit against the live library: tests/test_ss_rules.py) -- byte equality --
+plus properties and an analytic sphere.  oracle/raster_oracle.py is the older float-coordinate restatement of the GL pipeline
+(no sub-pixel snapping); it stays as an independent cross-check of the geometry."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import fixtures as Fx
 from oracle import raster_oracle as R
+from oracle import ss_rules as S
 
 
 @pytest.fixture(scope="module")
@@ -51,16 +54,16 @@ def test_hip_rasteriser_vs_oracle(se3, seed, subdiv, t):
     P = Fx.pose(seed, t)
     win = se3.HipRenderer.gl_window(P, Fx.K_YCB, 130.0)
     rgb, depth = ren.render(P, Fx.K_YCB, win)
-    orgb, odepth = R.render(*_mesh_args(m), P, Fx.K_YCB, win)
+    orgb, odepth = S.render_vispy(*_mesh_args(m), P, Fx.K_YCB, win, numpy_rule="numpy1")
     assert rgb.shape == (176, 176, 3) and depth.dtype == np.uint16
-    cover_same = (depth > 0) == (odepth > 0)
-    assert cover_same.mean() > 0.9995                      # identical coverage up to float ties on edges
-    both = (depth > 0) & (odepth > 0)
-    assert both.sum() > 2000
-    assert np.abs(depth[both].astype(int) - odepth[both].astype(int)).max() <= 1
-    drgb = np.abs(rgb[both].astype(int) - orgb[both].astype(int))
-    assert drgb.max() <= 2 and (drgb > 0).mean() < 0.02
+    assert (depth > 0).sum() > 2000
+    assert np.array_equal(depth, odepth) and np.array_equal(rgb, orgb)       # every byte
     assert (rgb[~(depth > 0)] == 0).all()                  # background exactly 0 (Tracker's maskA = depthA > 100)
+    # the float-coordinate restatement of the pipeline agrees up to what 1/16-pixel snapping moves
+    frgb, fdepth = R.render(*_mesh_args(m), P, Fx.K_YCB, win)
+    assert ((depth > 0) == (fdepth > 0)).mean() > 0.9995
+    both = (depth > 0) & (fdepth > 0)
+    assert np.abs(depth[both].astype(int) - fdepth[both].astype(int)).max() <= 1
     # deterministic (atomicMin on (depth | triangle id) keys)
     rgb2, depth2 = ren.render(P, Fx.K_YCB, win)
     assert (rgb2 == rgb).all() and (depth2 == depth).all()
@@ -145,20 +148,20 @@ def test_hip_full_frame_renderer_vs_pyrender_oracle(se3, tmp_path):
         P = Fx.pose(4, (0.01, -0.02, 0.45))
         rgb, depth = ren.render_frame(P, K)
         if textured:
-            orgb, odepth = R.render_frame(mesh["vertices"].astype(np.float32), None, mesh["faces"], P, K, W, H,
+            orgb, odepth = S.render_frame(mesh["vertices"].astype(np.float32), None, mesh["faces"], P, K, W, H,
                                           uv=mesh["uv"], texture=mesh["texture"], kd=mesh["kd"])
         else:
-            orgb, odepth = R.render_frame(model["vertices"].astype(np.float32), (model["colors"] / 255.0).astype(np.float32),
+            orgb, odepth = S.render_frame(model["vertices"].astype(np.float32), (model["colors"] / 255.0).astype(np.float32),
                                           model["faces"], P, K, W, H, kd=model["kd"])
         assert rgb.shape == (H, W, 3) and depth.dtype == np.uint16 and depth.shape == (H, W)
-        assert ((depth > 0) == (odepth > 0)).mean() > 0.9995
-        both = (depth > 0) & (odepth > 0)
-        assert both.sum() > 1500
-        assert np.abs(depth[both].astype(int) - odepth[both].astype(int)).max() <= 1
-        d = np.abs(rgb[both].astype(int) - orgb[both].astype(int))
-        # texture filtering: the level of detail is taken from finite differences at the pixel; identical algorithm,
-        # float32 rounding can move a texel boundary
-        assert np.median(d) <= 1 and (d > 6).mean() < 0.02, (np.median(d), (d > 6).mean())
+        assert (depth > 0).sum() > 1500 and np.array_equal(depth, odepth)          # coverage and depth: every pixel
+        d = np.abs(rgb.astype(int) - orgb.astype(int)).max(2)
+        if textured:
+            # the .obj loader numbers vertices by first use and the texture filter is float32 arithmetic on both sides: a texel
+            # boundary can move
+            assert np.median(d[depth > 0]) <= 1 and (d > 6).mean() < 0.02, (np.median(d), (d > 6).mean())
+        else:
+            assert np.array_equal(rgb, orgb)
         assert (rgb[~(depth > 0)] == 0).all()
         # the sphere's centre projects to (fx x/z + cx, fy y/z + cy): pixel i covers u in [i, i+1)
         ys, xs = np.nonzero(depth)
@@ -231,8 +234,9 @@ def _check_against_sphere(depth_mm, z, ndisc, what):
     assert abs(area - want) <= 0.01 * want + 8, (what, area, want)
     err = depth_mm[inner].astype(np.float64) - z[inner] * 1000.0
     # uint16 truncation (-1 .. 0) of a surface inscribed in the sphere: the facets lie <= 0.05 mm inside it at this
-    # tessellation, seen along the ray up to 1 / 0.35 times that at the edge of `inner`
-    assert err.min() > -1.0 - 1e-3 and err.max() < 0.25, (what, err.min(), err.max())
+    # tessellation, seen along the ray up to 1 / 0.35 times that at the edge of `inner`; GL interpolates depth from vertices
+    # snapped to 1/16 pixel (<= 1/32 pixel off), which at the edge of `inner` (2 mm of depth per pixel) is +-0.06 mm
+    assert err.min() > -1.0 - 0.1 and err.max() < 0.3, (what, err.min(), err.max())
 
 
 def test_oracle_vs_analytic_sphere():
