@@ -7,8 +7,11 @@ bench.py's `track` block; never by the product package.
 
 Per frame f, with P_f the pose fed in:
     HIP:     Q_f = tracker.on_track(P_f, rgb_f, depth_f)             (render -> crop -> normalise -> CNN -> pose)
-    oracle:  O.on_track(sd, P_f, rgb_f, depth_f, rgbA_f, depthA_f)   fed the SAME rendered image A (read back)
-    checks:  integer bbox identical (the only discrete decisions on the path),
+    oracle:  image A rendered ON THE ORACLE SIDE for P_f (oracle/ss_fast.py: the reference's renderer on the GL implementation of
+             the goldens, stated operation by operation and held to the goldens' bytes), then
+             O.on_track(sd, P_f, rgb_f, depth_f, rgbA_f, depthA_f) -- nothing of the HIP path enters the oracle's result
+             (round 5; before, the oracle was fed the HIP rasteriser's image and the renderer was outside the parity figure)
+    checks:  image A byte-identical; integer bbox identical (the only discrete decisions on the path),
              |d logits| (pre-tanh), |d(trans, rot)| <= 1e-4, |d pose| <= 1e-5  (the north-star tolerances).
     feedback (the loop of predict.py:529-564, prev_pose <- cur_pose, plus what keeps a random-init net in the frustum):
              R_{f+1} = R(Q_f)                          rotation: fully fed back, accumulates over the whole run
@@ -36,10 +39,28 @@ OBJECT_WIDTH_MM = 150.0
 HEAD_GAIN = 0.012        # random-init FC gain: logits spread ~0.07-0.4 over the frames once centred (see module docstring)
 N_DISTINCT_FRAMES = 16   # the observed frames cycle through this many synthetic 480x640 RGB-D images
 N_CALIB = 12             # frames of the bias calibration (oracle only)
+ORACLE_RENDER_EVERY = 16 # batched loops: every 16th pair's image A comes from the oracle's own renderer
 REGIMES = {              # name -> (trans_normalizer [m], rot_normalizer [rad])
     "ycb_video_5deg": (0.03, 5 * np.pi / 180),      # predict.py:128 defaults (predictSequenceYcb, :474)
     "ycbineoat_30deg": (0.03, 30 * np.pi / 180),    # predict.py:586
 }
+
+
+def oracle_mesh(mesh):
+    """the float32 arrays the reference class makes of a mesh given as arrays (vispy_renderer.py:113-132)"""
+    n = np.asarray(mesh["normals"], np.float64)
+    n = (n / np.linalg.norm(n, axis=1).reshape(-1, 1)).astype(np.float32)
+    return (np.asarray(mesh["vertices"], np.float32), n, (np.asarray(mesh["colors"], np.float64) / 255.0).astype(np.float32),
+            np.asarray(mesh["faces"]))
+
+
+def oracle_image_A(om, P, K, object_width, numpy_rule="numpy1"):
+    """Tracker.render_window (predict.py:193-208) on the oracle side: window from compute_bbox in the y-flipped image, then the
+    reference's renderer as oracle/ss_fast.py states it"""
+    from . import ss_fast as SF
+    bb = O.compute_bbox(P, K, object_width, scale=(1000, -1000, 1000))
+    win = (int(bb[:, 1].min()), int(bb[:, 0].min()), int(bb[:, 1].max()), int(bb[:, 0].max()))
+    return SF.render_vispy(om[0], om[1], om[2], om[3], P, K, win, numpy_rule=numpy_rule)
 
 
 def anchor(f):
@@ -93,6 +114,7 @@ def make_tracker(se3, subdiv=5, precision=None, regime="ycb_video_5deg", seq=Non
     trk.engine.load_state_dict(sd)
     if precision is not None:
         trk.engine.set_precision(precision)
+    trk.oracle_mesh = oracle_mesh(mesh)          # (test infrastructure rides along on the object)
     return trk, sd, (mean, std), len(mesh["faces"])
 
 
@@ -132,7 +154,7 @@ def run_regime(se3, regime, frames=300, check=True, subdiv=5, precision=None, ti
                    ms_p95=round(float(np.percentile(lat, 95)), 4), reinits=reinits)
     if check:
         P = P0.copy()
-        bbox_mismatch = reinits_c = 0
+        bbox_mismatch = reinits_c = imageA_identical = imageA_px = 0
         e_net = e_pose = e_logit = replay_diff = 0.0
         outs, bboxes = [], []
         rot_total = 0.0
@@ -140,8 +162,11 @@ def run_regime(se3, regime, frames=300, check=True, subdiv=5, precision=None, ti
             rgb, depth = seq[f % N_DISTINCT_FRAMES]
             Q = trk.on_track(P, rgb, depth)
             lg = trk.engine.logits(1).cpu().numpy()[0]
-            rgbA = trk.renderer.rgb.cpu().numpy()               # the image A this frame was computed from
-            depthA = trk.renderer.depth.cpu().numpy().view(np.uint16)
+            rgbA_hip = trk.renderer.rgb.cpu().numpy()           # the image A this frame was computed from
+            depthA_hip = trk.renderer.depth.cpu().numpy().view(np.uint16)
+            rgbA, depthA = oracle_image_A(trk.oracle_mesh, P, trk.K, trk.object_width, trk.engine.get_offset_rule())
+            imageA_identical += int(np.array_equal(rgbA, rgbA_hip) and np.array_equal(depthA, depthA_hip))
+            imageA_px += int((rgbA != rgbA_hip).any(2).sum() + (depthA != depthA_hip).sum())
             want, aux = O.on_track(sd, P, rgb, depth, rgbA, depthA, trk.K, trk.object_width, mean, std, tn, rn)
             bbox_mismatch += int(not np.array_equal(trk.last_prediction["bbox"], aux["bbox"]))
             got = np.r_[trk.last_prediction["trans"][0], trk.last_prediction["rot"][0]]
@@ -159,14 +184,15 @@ def run_regime(se3, regime, frames=300, check=True, subdiv=5, precision=None, ti
         signed = np.array(outs)
         outs = np.abs(signed)
         bboxes = np.array(bboxes)
-        out.update(frames_checked=frames, bbox_mismatches=bbox_mismatch, distinct_bboxes=int(len(np.unique(bboxes, axis=0))),
+        out.update(frames_checked=frames, renderer_inclusive=True, imageA_identical_frames=imageA_identical, imageA_differing_pixels=imageA_px,
+                   bbox_mismatches=bbox_mismatch, distinct_bboxes=int(len(np.unique(bboxes, axis=0))),
                    max_abs_logit_diff=e_logit, max_abs_trans_rot=e_net, max_abs_pose=e_pose,
                    median_abs_trans_rot=round(float(np.median(outs)), 4),
                    median_abs_trans=round(float(np.median(outs[:, :3])), 4), median_abs_rot=round(float(np.median(outs[:, 3:])), 4),
                    std_trans_rot=[round(float(v), 4) for v in signed.std(0)],
                    max_abs_output=round(float(outs.max()), 4),
                    accumulated_rotation_deg=round(rot_total * 180 / np.pi, 1), reinits_checked_pass=reinits_c,
-                   ok=bool(bbox_mismatch == 0 and e_net <= 1e-4 and e_logit <= 1e-4 and e_pose <= 1e-5))
+                   ok=bool(bbox_mismatch == 0 and e_net <= 1e-4 and e_logit <= 1e-4 and e_pose <= 1e-5 and imageA_identical == frames))
         if poses_timed is not None:
             out["timed_vs_checked_pass_max_abs_pose"] = replay_diff   # the two passes are the same deterministic track
     return out
@@ -197,7 +223,7 @@ def run_regime_batch(se3, regime, tracks, frames=50, subdiv=4, winograd=None, co
         Pk = Fx.pose(3 + k, (0.0, 0.0, 0.8))
         Pk[:3, 3] = anchor(phase[k])
         P.append(Pk)
-    bbox_mismatch = reinits = 0
+    bbox_mismatch = reinits = imageA_checked = imageA_identical = 0
     e_net = e_pose = e_logit = 0.0
     outs, bboxes = [], []
     launches = None
@@ -218,6 +244,11 @@ def run_regime_batch(se3, regime, tracks, frames=50, subdiv=4, winograd=None, co
         for k in range(n):
             rgbA = lp["rgbA"][k].cpu().numpy()
             depthA = lp["depthA"][k].cpu().numpy().view(np.uint16)
+            if (f * n + k) % ORACLE_RENDER_EVERY == 0:   # image A from the oracle's own renderer (all pairs would take minutes of numpy)
+                ra, da = oracle_image_A(trk.oracle_mesh, P[k], trk.K, trk.object_width, trk.engine.get_offset_rule())
+                imageA_checked += 1
+                imageA_identical += int(np.array_equal(ra, rgbA) and np.array_equal(da, depthA))
+                rgbA, depthA = ra, da
             bb = O.compute_bbox(P[k], trk.K, trk.object_width, scale=(1000, 1000, 1000))
             rgbB, depthB = O.crop_bbox(rgbs[k], deps[k], bb, (rgbA.shape[1], rgbA.shape[0]))
             a, b = O.process_data(rgbA, depthA, P[k], rgbB, depthB, mean, std)
@@ -250,15 +281,55 @@ def run_regime_batch(se3, regime, tracks, frames=50, subdiv=4, winograd=None, co
             P[k] = N
     signed = np.concatenate(outs, 0)
     out = {"trans_normalizer": tn, "rot_normalizer_deg": round(rn * 180 / np.pi, 3), "frames": frames, "tracks": n, "faces": nfaces,
-           "pairs_checked": frames * n, "bbox_mismatches": bbox_mismatch,
+           "pairs_checked": frames * n, "imageA_rendered_by_oracle": imageA_checked, "imageA_identical": imageA_identical,
+           "bbox_mismatches": bbox_mismatch,
            "distinct_bboxes": int(len(np.unique(np.array(bboxes), axis=0))),
            "max_abs_logit_diff": e_logit, "max_abs_trans_rot": e_net, "max_abs_pose": e_pose,
            "median_abs_trans_rot": round(float(np.median(np.abs(signed))), 4),
            "std_trans_rot": [round(float(v), 4) for v in signed.std(0)],
            "max_abs_output": round(float(np.abs(signed).max()), 4), "reinits": reinits, "launches": launches,
            "alt_max_abs_logit_diff": alt_err,
-           "ok": bool(bbox_mismatch == 0 and e_net <= 1e-4 and e_logit <= 1e-4 and e_pose <= 1e-5)}
+           "ok": bool(bbox_mismatch == 0 and e_net <= 1e-4 and e_logit <= 1e-4 and e_pose <= 1e-5 and imageA_identical == imageA_checked)}
     return out
+
+
+def golden_replay(se3):
+    """Image A of the HIP rasteriser against the COMMITTED outputs of the reference's own renderer (the unmodified VispyRenderer /
+    predict.Tracker on the goldens' GL implementation): tests/golden/gl_swiftshader*.npz (6 poses / meshes, both NumPy generations of
+    the depth read-back) and predict_tracker.npz (6 frames of predict.Tracker.render_window).  Byte equality, counted."""
+    import os
+    import tempfile
+    from .make_gl_golden import CASES, OBJECT_WIDTH, write_ply
+    from .make_predict_golden import FRAMES, MESH, OBJECT_WIDTH as PT_WIDTH
+    gd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    g2, g1 = np.load(os.path.join(gd, "gl_swiftshader.npz")), np.load(os.path.join(gd, "gl_swiftshader_numpy1.npz"))
+    gp = np.load(os.path.join(gd, "predict_tracker.npz"))
+    images = same = 0
+    eng = se3.Engine(0, 1)
+    with tempfile.TemporaryDirectory() as tmp:
+        for seed, subdiv, t in CASES:
+            ply = os.path.join(tmp, "m%d.ply" % seed)
+            write_ply(ply, Fx.icosphere(subdiv, 0.05, seed))
+            ren = se3.HipRenderer(eng, ply)
+            P = Fx.pose(seed, t)
+            win = se3.HipRenderer.gl_window(P, Fx.K_YCB, OBJECT_WIDTH)
+            for rule, g in (("numpy1", g1), ("numpy2", g2)):
+                eng.set_offset_rule(rule)
+                rgb, depth = ren.render(P, Fx.K_YCB, win)
+                images += 1
+                same += int(np.array_equal(rgb, g2["rgb_%d" % seed]) and np.array_equal(depth, g["depth_%d" % seed]))
+        ply = os.path.join(tmp, "model.ply")
+        write_ply(ply, Fx.icosphere(*MESH))
+        ren = se3.HipRenderer(eng, ply)
+        eng.set_offset_rule("numpy2")                        # predict_tracker.npz: the reference under this image's NumPy 2
+        for f in range(FRAMES):
+            P = gp["pose0"] if f == 0 else gp["poses"][f - 1]
+            rgb, depth = ren.render(P, Fx.K_YCB, se3.HipRenderer.gl_window(P, Fx.K_YCB, PT_WIDTH))
+            images += 1
+            same += int(np.array_equal(rgb, gp["rgbA"][f]) and np.array_equal(depth, gp["depthA"][f]))
+    return {"images": images, "byte_identical": same,
+            "source": "tests/golden/gl_swiftshader.npz, gl_swiftshader_numpy1.npz, predict_tracker.npz: the unmodified VispyRenderer / "
+                      "predict.Tracker.render_window on SwiftShader 4.1 (OpenGL ES 3.0)"}
 
 
 def run(se3, frames=300, check=True, subdiv=5, precision=None, timing=True, regimes=None):
@@ -271,7 +342,8 @@ def run(se3, frames=300, check=True, subdiv=5, precision=None, timing=True, regi
         per[name] = run_regime(se3, name, frames, check, subdiv, precision, timing and i == 0, seq)
     first = per[regimes[0]]
     out = {"frames": frames,
-           "renderer": "HIP rasteriser, %d-face vertex-colour mesh, image A stays on the device" % first["faces"],
+           "renderer": "HIP rasteriser, %d-face vertex-colour mesh, image A stays on the device; the oracle renders its own image A "
+                       "(the reference's VispyRenderer on the goldens' GL implementation, oracle/ss_fast.py)" % first["faces"],
            "sequence": "synthetic structured 480x640 RGB-D frames (%d distinct, cycled), random-init weights with calibrated FC "
                        "biases, rotation fed back frame to frame, translation step carried on a seeded anchor trajectory"
                        % N_DISTINCT_FRAMES}
@@ -281,7 +353,8 @@ def run(se3, frames=300, check=True, subdiv=5, precision=None, timing=True, regi
                            "D2H of the pose (one sync), as predict.py:217-296 without its GUI / second render")
     if check:
         vals = list(per.values())
-        out.update(frames_checked=sum(v["frames_checked"] for v in vals),
+        out.update(frames_checked=sum(v["frames_checked"] for v in vals), renderer_inclusive=True,
+                   imageA_identical_frames=sum(v["imageA_identical_frames"] for v in vals),
                    bbox_mismatches=sum(v["bbox_mismatches"] for v in vals),
                    max_abs_logit_diff=max(v["max_abs_logit_diff"] for v in vals),
                    max_abs_trans_rot=max(v["max_abs_trans_rot"] for v in vals),
@@ -289,5 +362,7 @@ def run(se3, frames=300, check=True, subdiv=5, precision=None, timing=True, regi
                    median_abs_trans_rot=min(v["median_abs_trans_rot"] for v in vals),
                    tol_trans_rot=1e-4, tol_pose=1e-5,
                    ok=all(v["ok"] for v in vals))
+        out["renderer_goldens"] = golden_replay(se3)
+        out["ok"] = bool(out["ok"] and out["renderer_goldens"]["byte_identical"] == out["renderer_goldens"]["images"])
     out["regimes"] = per
     return out

@@ -37,6 +37,8 @@ def se3():
 
 def _assert_regime(r, frames):
     assert r["frames_checked"] == frames
+    # renderer-inclusive: the oracle rendered its own image A every frame and the HIP rasteriser's was byte-identical
+    assert r["renderer_inclusive"] and r["imageA_identical_frames"] == frames and r["imageA_differing_pixels"] == 0, r
     assert r["bbox_mismatches"] == 0, r
     assert r["max_abs_logit_diff"] <= 1e-4 and r["max_abs_trans_rot"] <= 1e-4 and r["max_abs_pose"] <= 1e-5, r
     # the network output is exercised: not a constant, not saturated
@@ -86,6 +88,7 @@ def test_closed_loop_batched_tracks_run_the_large_batch_algorithms(se3, tracks, 
     if tracks == 64:
         assert sum("fused F(2x2)" in nm for nm in r["launches"]) == 4, r["launches"]
     assert r["pairs_checked"] == frames * tracks and r["bbox_mismatches"] == 0, r
+    assert r["imageA_rendered_by_oracle"] >= frames * tracks // 16 and r["imageA_identical"] == r["imageA_rendered_by_oracle"], r
     assert r["max_abs_logit_diff"] <= 1e-4 and r["max_abs_trans_rot"] <= 1e-4 and r["max_abs_pose"] <= 1e-5, r
     if tile is None:     # the default keeps at least a factor 2 under the binding tolerance
         assert r["max_abs_pose"] <= 5e-6, r
