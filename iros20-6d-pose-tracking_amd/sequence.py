@@ -1,12 +1,15 @@
-"""Headless sequence driver over the reference's YCB-Video directory layout:
-the loop of predict.py:446-575 `predictSequenceYcb` without the GUI.
+"""Headless sequence drivers over the reference's dataset layouts: the loops of predict.py without the GUI.
 
+YCB-Video (predict.py:446-575 `predictSequenceYcb`, :299-443 `getResultsYcb`, :88-123 `use_posecnn_res`):
     <seq_dir>/color/*.png            RGB uint8
     <seq_dir>/depth_filled/*.png     uint16 millimetres
     <seq_dir>/pose_gt/<class_id>/*.txt   4x4 object-in-camera, np.savetxt format
+    <ycb_dir>/image_sets/keyframe.txt, <ycb_dir>/YCB_Video_toolbox/results_PoseCNN_RSS2018/%06d.mat   (PoseCNN initialisation)
+    <ycb_dir>/YCB_Video_toolbox/PoseRBPF_Results/YCB_results_RGBD/<class folder>/seq_<k>/Pose*.txt    (PoseRBPF initialisation)
 
-Writes `<out_dir>/%05d.txt` (prediction) and `%05dgt.txt` exactly as predict.py:567-569 and returns
-the per-frame ADD / ADD-S errors, their AUCs (x100, eval_ycb.py) and the tracking rate."""
+predict_sequence_ycb writes `<out_dir>/%05d.txt` (prediction) and `%05dgt.txt` exactly as predict.py:567-569 and returns
+the per-frame ADD / ADD-S errors, their AUCs (x100, eval_ycb.py) and the tracking rate.  Checked against the UNMODIFIED
+reference drivers run on a synthetic tree (tests/golden/driver_ycbv.npz, tests/test_ycbv_drivers.py)."""
 import glob
 import os
 import time
@@ -15,9 +18,12 @@ import numpy as np
 from PIL import Image
 
 from . import metrics
+from . import utils as U
 
 
 def read_rgb(path):
+    """np.array(Image.open(path)) of predict.py:532 for the 3-channel PNGs of both datasets; a palette / RGBA / grey file is
+    converted to RGB here instead of reaching the kernels with another channel count."""
     return np.array(Image.open(path).convert("RGB"))
 
 
@@ -26,16 +32,118 @@ def read_depth_mm(path):
     return d.astype(np.uint16)
 
 
-def predict_sequence_ycb(tracker, seq_dir, class_id, out_dir, start_frame=0, reinit=None, max_frames=None):
-    """tracker: se3tracknet_amd.Tracker; reinit: optional {frame_index: 4x4 pose} (the reference
-    re-initialises from PoseCNN at listed frames, predict.py:539-541)."""
+def _keyframes(ycb_dir):
+    with open(os.path.join(ycb_dir, "image_sets", "keyframe.txt")) as ff:
+        return [line.rstrip() for line in ff]
+
+
+def _posecnn_pose(ycb_dir, class_id, index):
+    """poses_icp row of `class_id` in results_PoseCNN_RSS2018/%06d.mat -> 4x4 (predict.py:114-122 / :366-374)"""
+    import scipy.io
+    res = scipy.io.loadmat(os.path.join(ycb_dir, "YCB_Video_toolbox", "results_PoseCNN_RSS2018", "%06d.mat" % index))
+    row = np.where(res["rois"][:, 1] == class_id)
+    tmp = res["poses_icp"][row].reshape(-1)
+    if tmp.size < 7:
+        raise ValueError("PoseCNN result %06d.mat has no detection of class %d" % (index, class_id))
+    pose = np.eye(4)
+    pose[:3, :3] = U.quaternion_matrix(tmp[:4])[:3, :3]
+    pose[:3, 3] = tmp[4:7]
+    return pose
+
+
+def use_posecnn_res(ycb_dir, class_id, seq_frame_str):
+    """predict.py:88-123: the PoseCNN (+ICP) estimate of the keyframe NEAREST to 'SSSS/FFFFFF' -- the frame number is searched
+    outwards (n, then n+1 / n-1, n+2 / n-2 ...; the later frame wins a tie) in <ycb_dir>/image_sets/keyframe.txt, and the result
+    file is indexed by the keyframe's LINE NUMBER.  (The reference opens the keyframe list through an undefined global and the
+    result file through an absolute '/YCB_Video_toolbox/...' path, :90 / :114; both are read under ycb_dir here.)"""
+    seq_frames = _keyframes(ycb_dir)
+    seq_id, start_frame = int(seq_frame_str.split("/")[0]), int(seq_frame_str.split("/")[1])
+    in_seq = [f for f in seq_frames if f.startswith("%04d/" % seq_id)]
+    if not in_seq:
+        raise ValueError("no keyframe of sequence %04d in keyframe.txt (the reference loops forever here)" % seq_id)
+    neighbor = 0
+    while True:
+        tmp = "%04d/%06d" % (seq_id, start_frame + neighbor)
+        if tmp in seq_frames:
+            break
+        tmp = "%04d/%06d" % (seq_id, start_frame - neighbor)
+        if tmp in seq_frames:
+            break
+        neighbor += 1
+    return _posecnn_pose(ycb_dir, class_id, seq_frames.index(tmp))
+
+
+def find_class_videos_ycb(ycb_dir, class_id, testset=True):
+    """Utils.py:108-123 `findClassContainedVideosYcb`: ids of the videos under data_organized/ whose pose_gt/ has the class
+    (test set = 48..59)."""
+    out = []
+    for gt_dir in sorted(glob.glob(os.path.join(ycb_dir, "data_organized", "*", "pose_gt"))):
+        vid = int(os.path.basename(os.path.dirname(gt_dir)))
+        if testset and (vid < 48 or vid > 59):
+            continue
+        if class_id in [int(d) for d in os.listdir(gt_dir)]:
+            out.append(vid)
+    return out
+
+
+def poserbpf_pose(ycb_dir, class_id, seq_id):
+    """predict.py:375-390 / :500-516: first line of PoseRBPF_Results/YCB_results_RGBD/<class_id-th folder>/seq_<k>/Pose*.txt,
+    k = 1-based rank of seq_id among the test videos that contain the class; fields 2.. = translation, quaternion (w,x,y,z)."""
+    seqs = sorted(find_class_videos_ycb(ycb_dir, class_id, testset=True))
+    res_dir = os.path.join(ycb_dir, "YCB_Video_toolbox", "PoseRBPF_Results", "YCB_results_RGBD")
+    folders = sorted(os.listdir(res_dir))
+    cur = os.path.join(res_dir, folders[class_id - 1], "seq_%d" % (seqs.index(seq_id) + 1))
+    with open(glob.glob(os.path.join(cur, "Pose*.txt"))[0]) as ff:
+        pose = ff.readlines()[0].rstrip().split()[2:]
+    out = np.eye(4)
+    out[:3, 3] = [float(v) for v in pose[:3]]
+    out[:3, :3] = U.quaternion_matrix([float(v) for v in pose[3:7]])[:3, :3]
+    return out
+
+
+def predict_sequence_ycb(tracker, seq_dir, class_id, out_dir, start_frame=0, reinit=None, max_frames=None, init="gt",
+                         reinit_frames=None, ycb_dir=None, seq_id=None):
+    """tracker: se3tracknet_amd.Tracker.
+    init: 'gt' (what predict.py:447 hard-codes) | 'posecnn' (:480-496: start at the keyframe nearest to start_frame) | 'poserbpf'.
+    reinit_frames: the reference's --reinit_frames, a comma-separated string or list of 'SSSS/FFFFFF': before tracking the image
+    with index i (0-based; its YCB frame id is i + 1), if 'SSSS/%06d' % (i + 1) is listed, the pose fed in is the PoseCNN estimate
+    nearest to frame NUMBER i - 1 (predict.py:538-541, use_posecnn_res).  Needs ycb_dir (the dataset root) and seq_id (default:
+    the directory name).  reinit: alternatively {frame_index: 4x4 pose}."""
     rgb_files = sorted(glob.glob(os.path.join(seq_dir, "color", "*")))
     depth_files = sorted(glob.glob(os.path.join(seq_dir, "depth_filled", "*")))
     gt_files = sorted(glob.glob(os.path.join(seq_dir, "pose_gt", str(class_id), "*")))
     assert len(rgb_files) == len(depth_files) == len(gt_files) > start_frame, "incomplete sequence directory"
     gt_poses = [np.loadtxt(f) for f in gt_files]
+    if isinstance(reinit_frames, str):
+        reinit_frames = reinit_frames.split(",")
+    reinit_frames = list(reinit_frames or [])
+    if seq_id is None and (reinit_frames or init != "gt"):
+        seq_id = int(os.path.basename(os.path.normpath(seq_dir)))
+    if (reinit_frames or init != "gt") and ycb_dir is None:
+        raise ValueError("PoseCNN / PoseRBPF initialisation needs ycb_dir (image_sets/, YCB_Video_toolbox/)")
+    if init == "gt":
+        prev_pose = gt_poses[start_frame].copy()          # predict.py:478-479
+    elif init == "posecnn":                                # predict.py:480-496
+        seq_frames = _keyframes(ycb_dir)
+        neighbor = 0
+        while True:
+            s_ = "%04d/%06d" % (seq_id, start_frame + neighbor)
+            if s_ in seq_frames:
+                start_frame = start_frame + neighbor
+                break
+            s_ = "%04d/%06d" % (seq_id, start_frame - neighbor)
+            if s_ in seq_frames:
+                start_frame = start_frame - neighbor
+                break
+            neighbor += 1
+            if neighbor > 10 ** 6:
+                raise ValueError("no keyframe of sequence %04d" % seq_id)
+        prev_pose = use_posecnn_res(ycb_dir, class_id, s_)
+    elif init == "poserbpf":
+        prev_pose = poserbpf_pose(ycb_dir, class_id, seq_id)
+    else:
+        raise ValueError("init must be 'gt', 'posecnn' or 'poserbpf'")
     end = len(rgb_files) if max_frames is None else min(len(rgb_files), start_frame + 1 + max_frames)
-    prev_pose = gt_poses[start_frame].copy()          # init == 'gt' (predict.py:478-479)
     pred_poses = [prev_pose]
     os.makedirs(out_dir, exist_ok=True)
     t_track = 0.0
@@ -45,6 +153,8 @@ def predict_sequence_ycb(tracker, seq_dir, class_id, out_dir, start_frame=0, rei
         A_in_cam = prev_pose.copy()
         if reinit and i in reinit:
             A_in_cam = np.asarray(reinit[i], np.float64).copy()
+        if reinit_frames and "%04d/%06d" % (seq_id, i + 1) in reinit_frames:          # predict.py:538-541
+            A_in_cam = use_posecnn_res(ycb_dir, class_id, "%04d/%06d" % (seq_id, i - 1))
         t0 = time.perf_counter()
         cur_pose = tracker.on_track(A_in_cam, rgb, depth, gt_A_in_cam=gt_poses[i - 1], gt_B_in_cam=gt_poses[i])
         t_track += time.perf_counter() - t0
@@ -70,12 +180,16 @@ def predict_sequence_ycb(tracker, seq_dir, class_id, out_dir, start_frame=0, rei
 YCB_TEST_SEQUENCES = tuple(range(48, 60))   # predict.py:349 skips every video outside 0048..0059
 
 
-def get_results_ycb(tracker, ycb_dir, class_id, out_dir, seq_ids=YCB_TEST_SEQUENCES, max_frames=None):
+def get_results_ycb(tracker, ycb_dir, class_id, out_dir, seq_ids=YCB_TEST_SEQUENCES, max_frames=None, initialize_method="gt"):
     """The loop of predict.py:299-443 `getResultsYcb` (GT initialisation, no re-init, no video): every TEST
     sequence (48..59 by default, as predict.py:349; seq_ids=None takes every directory) under
     <ycb_dir>/data_organized/ that has pose_gt/<class_id>/ is tracked from its first frame and written as
     <out_dir>/seq<ID>/%07d.txt -- the layout eval_one_class / the reference's eval_ycb.py:95-96 parse
-    (file index = frame id - 1).  Returns {seq_id: n_poses}."""
+    (file index = frame id - 1).  initialize_method: 'gt' (what predict.py:301 hard-codes) | 'posecnn' (:362-373: the PoseCNN
+    result of the keyframe 'SSSS/000001') | 'poserbpf' (:374-390): two of the three result columns the reference publishes
+    start from those.  Returns {seq_id: n_poses}."""
+    if initialize_method not in ("gt", "posecnn", "poserbpf"):
+        raise ValueError("initialize_method must be 'gt', 'posecnn' or 'poserbpf'")
     root = os.path.join(ycb_dir, "data_organized")
     done = {}
     for seq_dir in sorted(glob.glob(os.path.join(root, "*"))):
@@ -89,7 +203,12 @@ def get_results_ycb(tracker, ycb_dir, class_id, out_dir, seq_ids=YCB_TEST_SEQUEN
         gt_files = sorted(glob.glob(os.path.join(seq_dir, "pose_gt", str(class_id), "*")))
         assert len(rgb_files) == len(depth_files) == len(gt_files) > 0, "incomplete sequence directory %s" % seq_dir
         n = len(rgb_files) if max_frames is None else min(len(rgb_files), max_frames)
-        prev_pose = np.loadtxt(gt_files[0])
+        if initialize_method == "posecnn":
+            prev_pose = _posecnn_pose(ycb_dir, class_id, _keyframes(ycb_dir).index("%04d/%06d" % (seq_id, 1)))
+        elif initialize_method == "poserbpf":
+            prev_pose = poserbpf_pose(ycb_dir, class_id, seq_id)
+        else:
+            prev_pose = np.loadtxt(gt_files[0])
         pred = [prev_pose]
         for i in range(1, n):
             cur = tracker.on_track(prev_pose, read_rgb(rgb_files[i]), read_depth_mm(depth_files[i]))

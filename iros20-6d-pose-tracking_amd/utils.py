@@ -382,3 +382,19 @@ def compute_obj_max_width(points):
     hull = ConvexHull(points)
     hp = points[hull.vertices]
     return float(np.max(distance_matrix(hp, hp))) * 1000
+
+
+def quaternion_matrix(quaternion):
+    """transformations.quaternion_matrix (C. Gohlke's transformations.py, which predict.py:118,372,389 call as T.quaternion_matrix):
+    homogeneous rotation matrix of the quaternion (w, x, y, z); |q|^2 below 4 eps gives the identity.  Third-party rule, restated
+    from the published algorithm (the package is not installable offline: parity unpinned, like cv2.Rodrigues)."""
+    q = np.array(quaternion, dtype=np.float64, copy=True)
+    n = np.dot(q, q)
+    if n < np.finfo(float).eps * 4.0:
+        return np.identity(4)
+    q *= np.sqrt(2.0 / n)
+    q = np.outer(q, q)
+    return np.array([[1.0 - q[2, 2] - q[3, 3], q[1, 2] - q[3, 0], q[1, 3] + q[2, 0], 0.0],
+                     [q[1, 2] + q[3, 0], 1.0 - q[1, 1] - q[3, 3], q[2, 3] - q[1, 0], 0.0],
+                     [q[1, 3] - q[2, 0], q[2, 3] + q[1, 0], 1.0 - q[1, 1] - q[2, 2], 0.0],
+                     [0.0, 0.0, 0.0, 1.0]])

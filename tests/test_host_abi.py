@@ -233,7 +233,8 @@ def test_model_points_and_object_width(se3, tmp_path):
     got = U.load_model_points(str(ply))
     assert np.abs(got - pts).max() < 1e-8
     ds = U.voxel_down_sample(got, 0.005)
-    assert len(ds) <= 500 and np.all(ds.min(0) >= pts.min(0) - 1e-9) and np.all(ds.max(0) <= pts.max(0) + 1e-9)
+    # (`property float` columns are float32, as plyfile / trimesh return them: 4e-9 at this magnitude)
+    assert len(ds) <= 500 and np.all(ds.min(0) >= pts.min(0) - 1e-8) and np.all(ds.max(0) <= pts.max(0) + 1e-8)
     w = U.compute_obj_max_width(ds)
     from scipy.spatial.distance import pdist
     assert abs(w - pdist(ds).max() * 1000) < 1e-6

@@ -1,0 +1,181 @@
+"""The YCB-Video drivers (BASELINE configs[2]'s code path) against the reference's own.  tests/golden/driver_ycbv.npz holds what the
+UNMODIFIED predict.predictSequenceYcb() (with --reinit_frames: PoseCNN re-initialisation), predict.getResultsYcb(),
+eval_ycb.eval_one_class() and predict.use_posecnn_res() produce on the synthetic tree of oracle/ycbv_fixtures.py
+(oracle/make_ycbv_golden.py: reference Tracker on torch-CPU, its VispyRenderer on SwiftShader, under this image's NumPy 2).
+CPU: the PoseCNN lookup, the re-initialisation rule, the file layouts, the evaluator (a stub tracker replays the reference's poses).
+GPU: the drop-in drivers with the drop-in Tracker AND its own rasteriser write the same files: image A byte-identical on every
+frame, poses within 1e-5, AUCs to 1e-9."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fixtures as Fx
+from oracle import se3_oracle as O
+from oracle import ycbv_fixtures as YF
+from oracle.make_predict_golden import HEAD_GAIN, MESH, OBJECT_WIDTH
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "driver_ycbv.npz"))
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    return YF.make_tree(str(tmp_path_factory.mktemp("ycbv")))
+
+
+@pytest.fixture(scope="module")
+def seq():
+    import importlib
+    return importlib.import_module("iros20-6d-pose-tracking_amd.sequence")
+
+
+class ReplayTracker:
+    """stands where the Tracker stands: returns the reference run's poses in order and records what it was fed"""
+    object_cloud = None
+
+    def __init__(self, poses_out):
+        self.out, self.fed, self.k = poses_out, [], 0
+
+    def on_track(self, prev_pose, rgb, depth, **kw):
+        assert rgb.shape == YF.FRAME_HW + (3,) and rgb.dtype == np.uint8 and depth.dtype == np.uint16
+        self.fed.append(np.array(prev_pose))
+        self.k += 1
+        return self.out[self.k - 1].copy()
+
+
+def test_golden_facts(golden):
+    assert [str(f) for f in golden["ycbv_files"]] == ["%05d.txt" % i for i in range(9)]
+    assert golden["ycbv_reinit_log"].tolist() == [4, 7]                          # image indices of 0048/000005 and 0048/000008
+    assert [str(f) for f in golden["res_files"]] == ["seq48/%07d.txt" % i for i in range(9)] + ["seq50/%07d.txt" % i for i in range(6)]
+    assert len(golden["eval_adi_errs"]) == 7                                     # keyframes of 0048 (4) and 0050 (3)
+    for i in range(9):
+        assert np.allclose(golden["ycbv_gt"][i], YF.gt_pose(48, i), atol=1e-15)
+    # pose feedback, except where the run re-initialised
+    for k in range(1, 8):
+        i = k + 1
+        if i in (4, 7):
+            assert np.abs(golden["ycbv_poses_in"][k] - golden["ycbv_poses"][k]).max() > 1e-3
+        else:
+            assert np.array_equal(golden["ycbv_poses_in"][k], golden["ycbv_poses"][k])
+
+
+def test_use_posecnn_res_equals_the_reference(golden, tree, seq):
+    for q, want in zip(golden["posecnn_queries"], golden["posecnn_poses"]):
+        got = seq.use_posecnn_res(tree, YF.CLASS_ID, str(q))
+        assert np.abs(got - want).max() < 1e-15, q
+    # the neighbour search: frame 2 -> keyframe 1 (n + 1 = 3 is none, n - 1 = 1 is), frame 3 -> 4 (the later frame wins), 8 -> 9
+    lines = YF.keyframe_lines()
+    for frame, key in ((2, 1), (3, 4), (5, 4), (6, 7), (8, 9)):
+        q, t = YF.posecnn_pose(48, key, YF.CLASS_ID)
+        got = seq.use_posecnn_res(tree, YF.CLASS_ID, "0048/%06d" % frame)
+        assert np.allclose(got[:3, 3], t, atol=1e-12), (frame, key, lines)
+    with pytest.raises(ValueError):
+        seq.use_posecnn_res(tree, YF.CLASS_ID, "0055/000001")                    # (the reference never returns here)
+
+
+def test_reinit_rule_and_file_layout_with_replayed_poses(golden, tree, seq, tmp_path):
+    trk = ReplayTracker(golden["ycbv_poses"][1:])
+    out = str(tmp_path / "out")
+    res = seq.predict_sequence_ycb(trk, os.path.join(tree, "data_organized", "0048"), YF.CLASS_ID, out,
+                                   reinit_frames=YF.REINIT_FRAMES, ycb_dir=tree)
+    assert sorted(f for f in os.listdir(out) if "gt" not in f) == [str(f) for f in golden["ycbv_files"]]
+    for i, f in enumerate(golden["ycbv_files"]):
+        assert np.array_equal(np.loadtxt(os.path.join(out, str(f))), golden["ycbv_poses"][i])
+        assert np.array_equal(np.loadtxt(os.path.join(out, str(f)[:-4] + "gt.txt")), golden["ycbv_gt"][i])
+    assert res["frames"] == 8
+    fed = np.array(trk.fed)
+    assert np.abs(fed - golden["ycbv_poses_in"]).max() < 1e-15                   # incl. the two PoseCNN re-initialisations
+    # getResultsYcb: test sequences with the class only (0010 is a training video, 0049 lacks the class)
+    trk2 = ReplayTracker(np.concatenate([golden["res_poses"][1:9], golden["res_poses"][10:]]))
+    rdir = str(tmp_path / "res")
+    done = seq.get_results_ycb(trk2, tree, YF.CLASS_ID, rdir)
+    assert done == {48: 9, 50: 6}
+    for i, f in enumerate(golden["res_files"]):
+        assert np.array_equal(np.loadtxt(os.path.join(rdir, str(f))), golden["res_poses"][i])
+    assert np.abs(np.array(trk2.fed) - golden["res_poses_in"]).max() < 1e-15
+    # eval_one_class on those files = the reference's evaluator on the reference's files
+    ev = seq.eval_one_class(rdir, tree, YF.CLASS_ID)
+    assert np.abs(ev["adi_errs"] - golden["eval_adi_errs"]).max() < 1e-12 and np.abs(ev["add_errs"] - golden["eval_add_errs"]).max() < 1e-12
+    assert abs(ev["adi_auc"] - float(golden["eval_adi_auc"])) < 1e-9 and abs(ev["add_auc"] - float(golden["eval_add_auc"])) < 1e-9
+
+
+def test_posecnn_and_poserbpf_initialisation(golden, tree, seq, tmp_path):
+    """the branches predict.py hard-codes away (initialize_method / init = 'gt'): same lookups as use_posecnn_res"""
+    trk = ReplayTracker([np.eye(4)] * 20)
+    seq.get_results_ycb(trk, tree, YF.CLASS_ID, str(tmp_path / "a"), initialize_method="posecnn")
+    assert np.abs(trk.fed[0] - seq.use_posecnn_res(tree, YF.CLASS_ID, "0048/000001")).max() == 0       # keyframe 'SSSS/000001'
+    trk = ReplayTracker([np.eye(4)] * 20)
+    seq.predict_sequence_ycb(trk, os.path.join(tree, "data_organized", "0048"), YF.CLASS_ID, str(tmp_path / "b"), start_frame=2,
+                             init="posecnn", ycb_dir=tree)
+    assert np.abs(trk.fed[0] - seq.use_posecnn_res(tree, YF.CLASS_ID, "0048/000002")).max() == 0 and len(trk.fed) == 9 - 1 - 1
+    # PoseRBPF: <class folder>/seq_<rank among the class's test videos>/Pose*.txt
+    base = os.path.join(tree, "YCB_Video_toolbox", "PoseRBPF_Results", "YCB_results_RGBD")
+    for k, name in enumerate(YF.CLASS_NAMES):
+        for r in (1, 2):
+            os.makedirs(os.path.join(base, name, "seq_%d" % r), exist_ok=True)
+            q, t = YF.posecnn_pose(48 + r, 1, k + 1)
+            with open(os.path.join(base, name, "seq_%d" % r, "Pose_%s.txt" % name), "w") as f:
+                f.write("1 %s %s %s\n" % (name, " ".join("%.17g" % v for v in t), " ".join("%.17g" % v for v in q)))
+    got = seq.poserbpf_pose(tree, YF.CLASS_ID, 50)                               # 0050 is the class's 2nd test video
+    q, t = YF.posecnn_pose(50, 1, YF.CLASS_ID)
+    from scipy.spatial.transform import Rotation
+    assert np.allclose(got[:3, 3], t) and np.allclose(got[:3, :3], Rotation.from_quat(np.r_[q[1:], q[0]]).as_matrix(), atol=1e-12)
+
+
+def test_golden_is_what_the_reference_drivers_compute_today(golden, tmp_path):
+    from oracle import ref_shims, swiftshader_gl as SG
+    if not (ref_shims.reference_available() and SG.available()):
+        pytest.skip("needs /root/reference and the kaleido wheel's SwiftShader")
+    from oracle import make_ycbv_golden as M
+    g = M.run(str(tmp_path))
+    assert np.array_equal(g["ycbv_rgbA"], golden["ycbv_rgbA"]) and np.array_equal(g["res_depthA"], golden["res_depthA"])
+    assert np.abs(g["ycbv_poses"] - golden["ycbv_poses"]).max() < 1e-6 and np.abs(g["res_poses"] - golden["res_poses"]).max() < 1e-6
+    assert abs(float(g["eval_adi_auc"]) - float(golden["eval_adi_auc"])) < 1e-3
+
+
+@pytest.mark.gpu
+def test_dropin_ycbv_drivers_write_what_the_reference_drivers_write(golden, tree, tmp_path):
+    import se3tracknet_amd as se3
+    from oracle.make_gl_golden import write_ply
+    sd = O.make_state_dict(0, head_gain=HEAD_GAIN)
+    mean, std = Fx.mean_std(0)
+    ply = str(tmp_path / "model.ply")
+    write_ply(ply, Fx.icosphere(*MESH))                                          # the model file the reference run was given
+    trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=OBJECT_WIDTH), mean, std, {"state_dict": sd}, model_path=ply)
+    trk.engine.set_offset_rule("numpy2")                                         # like for like: the golden ran under NumPy 2
+    seen = []
+    render = trk.renderer.render_device
+
+    def recording(ob2cam, K, window, *a, **k):
+        out = render(ob2cam, K, window, *a, **k)
+        seen.append((out[0].cpu().numpy().copy(), out[1].cpu().numpy().view(np.uint16).copy()))
+        return out
+    trk.renderer.render_device = recording
+    # ---- predictSequenceYcb with --reinit_frames ------------------------------------------------------------------------------
+    out = str(tmp_path / "out")
+    res = se3.sequence.predict_sequence_ycb(trk, os.path.join(tree, "data_organized", "0048"), YF.CLASS_ID, out,
+                                            reinit_frames=YF.REINIT_FRAMES, ycb_dir=tree)
+    assert sorted(f for f in os.listdir(out) if "gt" not in f) == [str(f) for f in golden["ycbv_files"]]
+    d = max(float(np.abs(np.loadtxt(os.path.join(out, str(f))) - golden["ycbv_poses"][i]).max()) for i, f in enumerate(golden["ycbv_files"]))
+    same = sum(int(np.array_equal(a, golden["ycbv_rgbA"][i]) and np.array_equal(b, golden["ycbv_depthA"][i])) for i, (a, b) in enumerate(seen))
+    print("predict_sequence_ycb vs predict.predictSequenceYcb (closed loop, 2 PoseCNN re-initialisations): %d / %d images A "
+          "byte-identical, max |d pose| %.2e, ADD-S AUC %.6f vs %.6f" % (same, len(seen), d, res["adi_auc"], float(golden["ycbv_adi_auc"])))
+    assert same == len(seen) == 8 and d < 1e-5
+    assert abs(res["adi_auc"] - float(golden["ycbv_adi_auc"])) < 1e-3           # (printed with 4 decimals by the reference; errors move by 1e-6)
+    # ---- getResultsYcb + eval_one_class ---------------------------------------------------------------------------------------------
+    seen.clear()
+    rdir = str(tmp_path / "res")
+    done = se3.sequence.get_results_ycb(trk, tree, YF.CLASS_ID, rdir)
+    assert done == {48: 9, 50: 6}
+    d2 = max(float(np.abs(np.loadtxt(os.path.join(rdir, str(f))) - golden["res_poses"][i]).max()) for i, f in enumerate(golden["res_files"]))
+    same2 = sum(int(np.array_equal(a, golden["res_rgbA"][i]) and np.array_equal(b, golden["res_depthA"][i])) for i, (a, b) in enumerate(seen))
+    ev = se3.sequence.eval_one_class(rdir, tree, YF.CLASS_ID)
+    print("get_results_ycb vs predict.getResultsYcb: %d / %d images A byte-identical, max |d pose| %.2e; eval_one_class ADD-S / ADD AUC "
+          "%.6f / %.6f vs the reference evaluator on the reference's files %.6f / %.6f" % (
+              same2, len(seen), d2, ev["adi_auc"], ev["add_auc"], float(golden["eval_adi_auc"]), float(golden["eval_add_auc"])))
+    assert same2 == len(seen) == 13 and d2 < 1e-5
+    assert np.abs(ev["adi_errs"] - golden["eval_adi_errs"]).max() < 2e-5 and np.abs(ev["add_errs"] - golden["eval_add_errs"]).max() < 2e-5
+    assert abs(ev["adi_auc"] - float(golden["eval_adi_auc"])) < 5e-3 and abs(ev["add_auc"] - float(golden["eval_add_auc"])) < 5e-3
