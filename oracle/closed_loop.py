@@ -366,3 +366,15 @@ def run(se3, frames=300, check=True, subdiv=5, precision=None, timing=True, regi
         out["ok"] = bool(out["ok"] and out["renderer_goldens"]["byte_identical"] == out["renderer_goldens"]["images"])
     out["regimes"] = per
     return out
+
+
+def images_close(seen, want_rgb, want_depth, exact):
+    """closed loop: identical where the pose fed in is; otherwise the pose differs from the reference run's in its 7th digit, and
+    when that moves ONE vertex across a 1/16-pixel rounding boundary the plane equations of its triangles change: some dozens of
+    pixels move by one colour step or one millimetre (measured: 0, 73 and 109 differing values among ~14,000 covered pixels)"""
+    for i, (a, b) in enumerate(seen):
+        nd = int((a != want_rgb[i]).any(2).sum() + (b != want_depth[i]).sum())
+        assert nd == 0 if i in exact else nd <= 1000, (i, nd)
+        both = (b > 0) & (want_depth[i] > 0)
+        assert ((b > 0) != (want_depth[i] > 0)).sum() <= 12 and np.abs(b[both].astype(int) - want_depth[i][both].astype(int)).max() <= 1
+        assert np.abs(a[both].astype(int) - want_rgb[i][both].astype(int)).max() <= 3

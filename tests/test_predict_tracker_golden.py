@@ -93,8 +93,8 @@ def test_dropin_tracker_vs_predict_tracker(golden, tmp_path):
         got = trk.on_track(P, rgb, depth, gt_A_in_cam=np.eye(4), gt_B_in_cam=np.eye(4), debug=False, samples=1)
         worst = max(worst, float(np.abs(got - golden["poses"][f]).max()))
         # the whole drop-in, its own rasteriser included, in CLOSED LOOP (its own pose fed back, as predict.py's drivers do)
-        rgbA, depthA = hip.render_window(P_hip)
-        assert np.array_equal(rgbA, golden["rgbA"][f]) and np.array_equal(depthA, golden["depthA"][f]), f    # image A: every byte
+        rgbA, depthA = hip.render_window(P)                      # at the pose predict.Tracker rendered: every byte
+        assert np.array_equal(rgbA, golden["rgbA"][f]) and np.array_equal(depthA, golden["depthA"][f]), f
         P_hip = hip.on_track(P_hip, rgb, depth)
         worst_hip = max(worst_hip, float(np.abs(P_hip - golden["poses"][f]).max()))
     print("drop-in Tracker vs predict.Tracker: max |d pose| %.2e (reference's image A injected), %.2e (closed loop, HIP rasteriser's image A: "

@@ -3,8 +3,9 @@ UNMODIFIED predict.predictSequenceYcb() (with --reinit_frames: PoseCNN re-initia
 eval_ycb.eval_one_class() and predict.use_posecnn_res() produce on the synthetic tree of oracle/ycbv_fixtures.py
 (oracle/make_ycbv_golden.py: reference Tracker on torch-CPU, its VispyRenderer on SwiftShader, under this image's NumPy 2).
 CPU: the PoseCNN lookup, the re-initialisation rule, the file layouts, the evaluator (a stub tracker replays the reference's poses).
-GPU: the drop-in drivers with the drop-in Tracker AND its own rasteriser write the same files: image A byte-identical on every
-frame, poses within 1e-5, AUCs to 1e-9."""
+GPU: the drop-in drivers with the drop-in Tracker AND its own rasteriser write the same files in CLOSED LOOP: poses within 1e-5;
+image A byte-identical wherever the pose fed in is (initial / re-initialised frames, and every frame when the reference run's
+poses are fed: a pose that differs in its 7th digit can legitimately move a silhouette pixel or a millimetre boundary)."""
 import os
 
 import numpy as np
@@ -13,6 +14,7 @@ import pytest
 from oracle import fixtures as Fx
 from oracle import se3_oracle as O
 from oracle import ycbv_fixtures as YF
+from oracle.closed_loop import images_close as _images_close
 from oracle.make_predict_golden import HEAD_GAIN, MESH, OBJECT_WIDTH
 
 
@@ -163,7 +165,12 @@ def test_dropin_ycbv_drivers_write_what_the_reference_drivers_write(golden, tree
     same = sum(int(np.array_equal(a, golden["ycbv_rgbA"][i]) and np.array_equal(b, golden["ycbv_depthA"][i])) for i, (a, b) in enumerate(seen))
     print("predict_sequence_ycb vs predict.predictSequenceYcb (closed loop, 2 PoseCNN re-initialisations): %d / %d images A "
           "byte-identical, max |d pose| %.2e, ADD-S AUC %.6f vs %.6f" % (same, len(seen), d, res["adi_auc"], float(golden["ycbv_adi_auc"])))
-    assert same == len(seen) == 8 and d < 1e-5
+    assert len(seen) == 8 and d < 1e-5
+    _images_close(seen, golden["ycbv_rgbA"], golden["ycbv_depthA"], exact=(0, 3, 6))          # GT start + the two PoseCNN poses
+    for k in range(8):                                                                           # the reference run's own poses: every byte
+        rgbA, depthA = trk.render_window(golden["ycbv_poses_in"][k])
+        assert np.array_equal(rgbA, golden["ycbv_rgbA"][k]) and np.array_equal(depthA, golden["ycbv_depthA"][k]), k
+    seen.clear()
     assert abs(res["adi_auc"] - float(golden["ycbv_adi_auc"])) < 1e-3           # (printed with 4 decimals by the reference; errors move by 1e-6)
     # ---- getResultsYcb + eval_one_class ---------------------------------------------------------------------------------------------
     seen.clear()
@@ -176,6 +183,10 @@ def test_dropin_ycbv_drivers_write_what_the_reference_drivers_write(golden, tree
     print("get_results_ycb vs predict.getResultsYcb: %d / %d images A byte-identical, max |d pose| %.2e; eval_one_class ADD-S / ADD AUC "
           "%.6f / %.6f vs the reference evaluator on the reference's files %.6f / %.6f" % (
               same2, len(seen), d2, ev["adi_auc"], ev["add_auc"], float(golden["eval_adi_auc"]), float(golden["eval_add_auc"])))
-    assert same2 == len(seen) == 13 and d2 < 1e-5
+    assert len(seen) == 13 and d2 < 1e-5
+    _images_close(seen, golden["res_rgbA"], golden["res_depthA"], exact=(0, 8))                # the two GT-initialised first frames
+    for k in range(13):
+        rgbA, depthA = trk.render_window(golden["res_poses_in"][k])
+        assert np.array_equal(rgbA, golden["res_rgbA"][k]) and np.array_equal(depthA, golden["res_depthA"][k]), k
     assert np.abs(ev["adi_errs"] - golden["eval_adi_errs"]).max() < 2e-5 and np.abs(ev["add_errs"] - golden["eval_add_errs"]).max() < 2e-5
     assert abs(ev["adi_auc"] - float(golden["eval_adi_auc"])) < 5e-3 and abs(ev["add_auc"] - float(golden["eval_add_auc"])) < 5e-3
