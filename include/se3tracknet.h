@@ -237,6 +237,19 @@ int se3tn_mesh_set_texture(se3tn_mesh* mesh, const float* uv, const uint8_t* rgb
 int se3tn_render_frame(se3tn_ctx* ctx, se3tn_mesh* mesh, const double ob_in_cam[16], const double K[9], int W, int H,
                        uint8_t* rgb, uint16_t* depth, void* stream);
 
+/* ---- one frame of Tracker.on_track in ONE call -------------------------------------------------------- */
+/* predict.py:217-296 for samples == 1, with the model mesh rendered by this library: compute_bbox (host float64) -> image A
+ * (se3tn_render at the y-flipped window, :193-208) -> crop + normalise of image A and of the camera frame (ONE launch) -> network ->
+ * pose update -> read-back.  rgb / depth are HOST pointers to the camera frame (uint8 [H,W,3] RGB, uint16 [H,W] millimetres):
+ * only the rows / columns the crop window covers are staged (pinned) and uploaded, in one copy together with the pose.
+ * rgbA_dev / depthA_dev: optional device buffers (uint8 [176,176,3], uint16 [176,176]) that receive image A (NULL: internal).
+ * Outputs are host memory: pose_out = the 4x4 float64 estimate (row-major); trans_out / rot_out [3] (may be NULL) the network's
+ * tanh outputs; bbox_vu [4][2] (may be NULL) compute_bbox's corners.  SYNCHRONOUS on `stream` (as predict.py:275-276 is); the first
+ * call (or a larger frame) allocates the staging buffers.  Same arithmetic as se3tn_render + se3tn_preprocess x2 + se3tn_infer. */
+int se3tn_on_track(se3tn_ctx* ctx, se3tn_mesh* mesh, const double prev_pose[16], const double K[9], double object_width_mm,
+                   const uint8_t* rgb, const uint16_t* depth, int H, int W, uint8_t* rgbA_dev, uint16_t* depthA_dev,
+                   double pose_out[16], float trans_out[3], float rot_out[3], int32_t bbox_vu[8], void* stream);
+
 /* ---- live-camera front end: depth hole filling ---------------------------------------------------- */
 /* Utils.py:455-514 `fill_depth` as predict_ros.py:38-41 applies it to every depth frame before on_track:
  *     depth = fill_depth(depth_mm / 1e3, max_depth, extrapolate, blur_type);  out_mm = (depth * 1000).astype(uint16)

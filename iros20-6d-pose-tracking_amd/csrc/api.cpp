@@ -70,6 +70,9 @@ struct se3tn_ctx {
   int gemmp = -1;                               // SE3TN_WINO_GEMMP = 0 | 1: never | always the persistent 128 x 256 Winograd GEMM (default: by tile count)
   bool wino_fuse = true;                        // whole residual blocks as one fused launch sequence (SE3TN_WINOGRAD_FUSE=0: conv by conv)
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
+  int* splitk_sem = nullptr;                    // [2 x SE3TN_SPLITK_MAX_TILES] arrival / seen counters of the fused split-K reduction (zero between launches)
+  bool splitk_fused = false;                    // SE3TN_SPLITK_FUSED=1 (developer switch): the reduction inside the split-K launch -- bitwise the same results,
+                                                // but SLOWER on this chip (363 vs 268 us per batch-1 forward: EXPERIMENTS item 41), so off
   size_t part_bytes = 0;
   // Winograd F(m x m,3x3) path (wino_mfma.hip) of convAB2.* and trans|rot conv2.* at n >= wino_min_batch
   int wino_min_batch = SE3TN_WINOGRAD_DEFAULT_MIN_BATCH;  // 0 = never
@@ -96,6 +99,10 @@ struct se3tn_ctx {
   int prec = SE3TN_PREC_F32;                    // se3tn_set_precision
   int offset_rule = SE3TN_OFFSET_RULE_NUMPY1;   // se3tn_set_offset_rule
   int raster_sub_bits = 4;                      // se3tn_set_raster_rule: sub-pixel bits of the rasteriser's window coordinates
+  // se3tn_on_track: pinned host staging [pose 128 B | frame window rgb | depth], its device mirror, device outputs and their pinned copy
+  uint8_t* trk_host = nullptr; uint8_t* trk_dev = nullptr; size_t trk_bytes = 0;
+  uint8_t* trk_out_dev = nullptr; uint8_t* trk_out_host = nullptr;
+  uint8_t* trk_rgbA = nullptr; uint16_t* trk_depthA = nullptr;
   int in_split[2] = {0, 0};                     // pixel format currently held by inA / inB
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
   int* overflow = nullptr;                      // device flag: a split-row store left the f16 range
@@ -125,8 +132,8 @@ struct se3tn_mesh {
   int* faces = nullptr;
   float4* vpost = nullptr;  // [V] clip positions, [V] snapped window coordinates (raster_vertex_kernel)
   int4* vsnap = nullptr;
-  int* big = nullptr;     // [1 + F] queue of large triangles (raster_big_kernel)
-  int* clipq = nullptr;   // [1 + F] queue of triangles that cross the frustum (raster_clip_kernel)
+  int* big = nullptr;     // [1 + F] queue of large triangles (raster_queue_kernel)
+  int* clipq = nullptr;   // [1 + F] queue of triangles that cross the frustum (raster_queue_kernel)
   int V = 0, F = 0;
   // pyrender-style material (se3tn_mesh_set_texture): uv per vertex, RGB mip pyramid, Kd
   float* uv = nullptr;
@@ -353,6 +360,9 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
     // split-K workspace: 16 slices of the widest layer (1024 couts x 121 px) up to batch 16
     c->part_bytes = (size_t)16 * 1024 * 121 * 16 * sizeof(float);
     e = hipMalloc((void**)&c->part, c->part_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->splitk_sem, sizeof(int) * 2 * SE3TN_SPLITK_MAX_TILES);
+    if (e == hipSuccess) e = hipMemset(c->splitk_sem, 0, sizeof(int) * 2 * SE3TN_SPLITK_MAX_TILES);
+    if (const char* sf = std::getenv("SE3TN_SPLITK_FUSED")) c->splitk_fused = std::atoi(sf) != 0;
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(split-K workspace)"); }
     e = hipMalloc((void**)&c->zbuf, sizeof(unsigned long long) * RES * RES);
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(zbuf)"); }
@@ -371,7 +381,7 @@ void se3tn_destroy(se3tn_ctx* c) {
   if (!c) return;
   if (c->device >= 0) {
     float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
-                     c->head_t, c->head_f, c->logits, c->fcpart, c->part, c->blob_owned, c->split_w, c->wino_v, c->wino_m,
+                     c->head_t, c->head_f, c->logits, c->fcpart, c->part, (float*)c->splitk_sem, c->blob_owned, c->split_w, c->wino_v, c->wino_m,
                      c->wino_u[0], c->wino_u[1], c->wino_u[2], c->wino_u[3], c->wino_u6[0], c->wino_u6[1], c->wino_u6[2], c->wino_u6[3],
                      c->wino_us[0], c->wino_us[1], c->wino_us[2], c->wino_us[3], c->wino_usc[0], c->wino_usc[1], c->wino_usc[2],
                      c->wino_usc[3], c->wino64_u[0], c->wino64_u[1], c->wino64_u[2], c->wino64_u[3]};
@@ -380,6 +390,10 @@ void se3tn_destroy(se3tn_ctx* c) {
     for (auto& g : c->graphs)
       if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (c->overflow) (void)hipFree(c->overflow);
+    if (c->trk_host) (void)hipHostFree(c->trk_host);
+    if (c->trk_out_host) (void)hipHostFree(c->trk_out_host);
+    for (void* b : {(void*)c->trk_dev, (void*)c->trk_out_dev, (void*)c->trk_rgbA, (void*)c->trk_depthA})
+      if (b) (void)hipFree(b);
     if (c->zbuf) (void)hipFree(c->zbuf);
     if (c->fd_buf) (void)hipFree(c->fd_buf);
     for (int s = 0; s < c->slots; ++s)
@@ -592,6 +606,7 @@ int se3tn_preprocess(se3tn_ctx* c, const se3tn_crop* crops, int n, float* out, v
     a.offset_rule = c->offset_rule;
     if (a.padded) c->in_split[out == c->inA ? 0 : 1] = a.split;
     a.out = out + (size_t)i0 * (a.padded ? IN_P * IN_P : RES * RES) * 4;
+    a.out2 = nullptr; a.n_first = a.n;
     HIPCHK(launch_preprocess(a, (hipStream_t)stream));
   }
   return SE3TN_OK;
@@ -776,6 +791,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
       a.w = WS + SL.conv_ws[id];
       a.wscale = WS + SL.conv_sc[id];
     } a.res = res; a.out = out; a.part = c->part; a.part_bytes = c->part_bytes;
+    a.sem = c->splitk_fused ? c->splitk_sem : nullptr;
     a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
     a.H = hin; a.W = hin; a.Ho = (hin - 1) / stride + 1; a.Wo = a.Ho;
     a.M = n * a.Ho * a.Wo;
@@ -1038,6 +1054,110 @@ int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const 
   return SE3TN_OK;
 }
 
+// np.round: round half to even
+static double round_half_even(double x) { return std::nearbyint(x); }
+
+// Utils.py:302-316 compute_bbox with scale (1000, sy, 1000) -> (left, top, right, bottom) = min / max of the (u, v) corners
+static void bbox_window(const double pose[16], const double K[9], double width, double sy, int32_t win[4], int32_t vu[8]) {
+  const double x = pose[3] * 1000, y = pose[7] * sy, z = pose[11] * 1000, off = width / 2;
+  const double px[4] = {x - off, x - off, x + off, x + off};
+  const double py[4] = {y - off, y + off, y - off, y + off};
+  int32_t umin = INT32_MAX, umax = INT32_MIN, vmin = INT32_MAX, vmax = INT32_MIN;
+  for (int i = 0; i < 4; ++i) {
+    const int32_t u = (int32_t)round_half_even(px[i] * K[0] / z + K[2]);
+    const int32_t v = (int32_t)round_half_even(py[i] * K[4] / z + K[5]);
+    if (vu) { vu[2 * i] = v; vu[2 * i + 1] = u; }
+    umin = u < umin ? u : umin; umax = u > umax ? u : umax;
+    vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
+  }
+  win[0] = umin; win[1] = vmin; win[2] = umax; win[3] = vmax;
+}
+
+int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], const double K[9], double object_width_mm,
+                   const uint8_t* rgb, const uint16_t* depth, int H, int W, uint8_t* rgbA_dev, uint16_t* depthA_dev,
+                   double pose_out[16], float trans_out[3], float rot_out[3], int32_t bbox_vu[8], void* stream) {
+  if (!c || c->device < 0 || !m || !prev_pose || !K || !rgb || !depth || H < 1 || W < 1 || !pose_out || !(object_width_mm > 0))
+    return fail(SE3TN_E_ARG, "se3tn_on_track: bad argument");
+  if (!c->have_norm) return fail(SE3TN_E_STATE, "se3tn_on_track: call se3tn_set_normalization first");
+  hipStream_t st = (hipStream_t)stream;
+  // start-up allocations (first call / larger frame): pinned staging for a whole frame, its device mirror, outputs
+  const size_t need = 256 + (size_t)H * W * 5 + 64;
+  if (need > c->trk_bytes) {
+    HIPCHK(hipDeviceSynchronize());
+    if (c->trk_host) HIPCHK(hipHostFree(c->trk_host));
+    if (c->trk_dev) HIPCHK(hipFree(c->trk_dev));
+    c->trk_host = nullptr; c->trk_dev = nullptr; c->trk_bytes = 0;
+    HIPCHK(hipHostMalloc((void**)&c->trk_host, need, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&c->trk_dev, need));
+    c->trk_bytes = need;
+  }
+  if (!c->trk_out_dev) {
+    HIPCHK(hipMalloc((void**)&c->trk_out_dev, 256));
+    HIPCHK(hipHostMalloc((void**)&c->trk_out_host, 256, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&c->trk_rgbA, (size_t)RES * RES * 3));
+    HIPCHK(hipMalloc((void**)&c->trk_depthA, (size_t)RES * RES * 2));
+  }
+  // predict.py:231-235: bbox of the previous pose (host float64, round half to even) -> crop window of image B;
+  // :201-206: the same with the y axis flipped -> the renderer's window
+  int32_t winB[4], winA[4], vu[8];
+  bbox_window(prev_pose, K, object_width_mm, 1000.0, winB, vu);
+  bbox_window(prev_pose, K, object_width_mm, -1000.0, winA, nullptr);
+  if (winB[2] <= winB[0] || winB[3] <= winB[1]) return fail(SE3TN_E_ARG, "se3tn_on_track: empty crop window (pose behind the camera?)");
+  // only the part of the frame the window covers travels: rows / columns [y0, y1) x [x0, x1) into pinned memory, ONE copy
+  // with the pose in front.  crop_bbox's canvas is zero outside the frame (Utils.py:327-342): outside this sub-image too.
+  int x0 = winB[0] > 0 ? winB[0] : 0, x1 = winB[2] < W ? winB[2] : W;
+  int y0 = winB[1] > 0 ? winB[1] : 0, y1 = winB[3] < H ? winB[3] : H;
+  int sw = x1 - x0, sh = y1 - y0;
+  uint8_t* hp = c->trk_host;
+  std::memcpy(hp, prev_pose, 128);
+  uint8_t* h_rgb = hp + 256;
+  const bool miss = sw <= 0 || sh <= 0;   // the window misses the frame: a 1 x 1 zero sub-image it does not touch
+  if (miss) { sw = sh = 1; x0 = winB[0] - 8; y0 = winB[1] - 8; }
+  const size_t d_off = 256 + (((size_t)sw * sh * 3 + 63) & ~(size_t)63);
+  if (miss) {
+    std::memset(h_rgb, 0, 3);
+    std::memset(hp + d_off, 0, 2);
+  } else {
+    for (int y = 0; y < sh; ++y) {
+      std::memcpy(h_rgb + (size_t)y * sw * 3, rgb + ((size_t)(y0 + y) * W + x0) * 3, (size_t)sw * 3);
+      std::memcpy(hp + d_off + (size_t)y * sw * 2, depth + (size_t)(y0 + y) * W + x0, (size_t)sw * 2);
+    }
+  }
+  const size_t bytes = d_off + (size_t)sw * sh * 2;
+  HIPCHK(hipMemcpyAsync(c->trk_dev, hp, bytes, hipMemcpyHostToDevice, st));
+  uint8_t* rA = rgbA_dev ? rgbA_dev : c->trk_rgbA;
+  uint16_t* dA = depthA_dev ? depthA_dev : c->trk_depthA;
+  if (int rc = se3tn_render(c, m, prev_pose, K, winA, rA, dA, stream)) return rc;
+  // image A and image B in ONE preprocess launch (data_augmentation.py:124-189 for both, with poseA's z)
+  CropArgs a;
+  std::memcpy(a.mean, c->mean, sizeof(a.mean));
+  std::memcpy(a.stdv, c->stdv, sizeof(a.stdv));
+  const double z_mm = prev_pose[11] * 1000;
+  se3tn_crop& ca = a.c[0];
+  ca.rgb = rA; ca.depth = dA; ca.H = RES; ca.W = RES; ca.left = 0; ca.top = 0; ca.right = RES; ca.bottom = RES;
+  ca.z_offset_mm = z_mm; ca.stats = 0; ca._pad = 0;
+  se3tn_crop& cb = a.c[1];
+  cb.rgb = c->trk_dev + 256; cb.depth = (const uint16_t*)(c->trk_dev + d_off); cb.H = sh; cb.W = sw;
+  cb.left = winB[0] - x0; cb.top = winB[1] - y0; cb.right = winB[2] - x0; cb.bottom = winB[3] - y0;
+  cb.z_offset_mm = z_mm; cb.stats = 1; cb._pad = 0;
+  a.n = 2; a.n_first = 1; a.out = c->inA; a.out2 = c->inB; a.padded = 1;
+  a.split = c->prec == SE3TN_PREC_F16X3 ? 1 : 0;
+  a.overflow = c->overflow; a.offset_rule = c->offset_rule;
+  c->in_split[0] = c->in_split[1] = a.split;
+  HIPCHK(launch_preprocess(a, st));
+  float* trans_d = (float*)(c->trk_out_dev + 128);
+  float* rot_d = (float*)(c->trk_out_dev + 144);
+  if (int rc = se3tn_infer(c, c->inA, c->inB, 1, SE3TN_NHWC, trans_d, rot_d, (const double*)c->trk_dev, (double*)c->trk_out_dev, stream))
+    return rc;
+  HIPCHK(hipMemcpyAsync(c->trk_out_host, c->trk_out_dev, 160, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::memcpy(pose_out, c->trk_out_host, 128);
+  if (trans_out) std::memcpy(trans_out, c->trk_out_host + 128, 12);
+  if (rot_out) std::memcpy(rot_out, c->trk_out_host + 144, 12);
+  if (bbox_vu) std::memcpy(bbox_vu, vu, sizeof(vu));
+  return SE3TN_OK;
+}
+
 int se3tn_fill_depth(se3tn_ctx* c, const uint16_t* depth_mm, int H, int W, double max_depth_m, int extrapolate, int blur,
                      uint16_t* out_mm, float* out_m, void* stream) {
   if (!c || c->device < 0 || !depth_mm || H < 1 || W < 1 || (!out_mm && !out_m) || blur < 0 || blur > 2)
@@ -1150,8 +1270,6 @@ int se3tn_profile_launches(se3tn_ctx* c, int slot, int cap, const char** names, 
 }
 
 // ---- host-side float64 pieces -----------------------------------------------------------------
-// np.round: round half to even
-static double round_half_even(double x) { return std::nearbyint(x); }
 
 int se3tn_compute_bbox(const double pose[16], const double K[9], double width, int32_t out_vu[8]) {
   if (!pose || !K || !out_vu) return fail(SE3TN_E_ARG, "se3tn_compute_bbox: bad argument");

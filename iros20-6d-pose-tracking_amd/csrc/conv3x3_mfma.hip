@@ -402,6 +402,130 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_gather_s2_kernel(const Con
   store_tiles<PT, CT, EPI, MM, OUTF, FMT_F32>(a, g, acc, opix, ok, n0 + wn * CT * 32, hh);
 }
 
+// 16-byte store with device (agent) scope: written through the non-coherent per-XCD L2, visible to every compute unit once
+// s_waitcnt vmcnt(0) has returned
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_agent_scope(float* p, const float4 v) {
+  f32x4_t t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+}
+
+#ifndef SE3TN_SPLITK_WT
+#define SE3TN_SPLITK_WT 0   // 1: partial sums written through the L2 (any XCD may read them); 0: left in the tile's own XCD's L2
+#endif
+// the arrival counters: device scope (memory side) with write-through partial sums, the XCD's own L2 otherwise
+#if SE3TN_SPLITK_WT
+#define SE3TN_SEM_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#else
+#define SE3TN_SEM_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+__device__ __forceinline__ void store_partial(float* p, const float4 v) {
+#if SE3TN_SPLITK_WT
+  store_agent_scope(p, v);
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
+// one float4 of the output: the slices' partial sums added in a FIXED order, then bias / residual / activation
+template <int EPI, int MM, int OUTF, int RESF>
+__device__ __forceinline__ void reduce_element(const ConvArgs& a, const float* src, size_t slice_stride, int g, int m, int c) {
+  float4 v = *reinterpret_cast<const float4*>(src);
+#pragma unroll 8
+  for (int s = 1; s < a.slices; ++s) {  // fixed order: deterministic (unrolled: the loads of 8 slices are in flight together)
+    const float4 u = *reinterpret_cast<const float4*>(src + s * slice_stride);
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  if (MM == MM_F16X3) {
+    const float4 w = *reinterpret_cast<const float4*>(a.wscale + (size_t)g * a.bias_gs + c);
+    v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
+  }
+  const size_t opix = (size_t)padded_index(m, a.Ho * a.Wo, a.Wo);
+  const float4 b = *reinterpret_cast<const float4*>(a.bias + (size_t)g * a.bias_gs + c);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI == 1) {
+    const float* res = a.res + (size_t)g * a.res_gs;
+    r = (RESF == FMT_SPLIT) ? load_split4(res, opix, a.res_ld, c) : *reinterpret_cast<const float4*>(res + opix * a.res_ld + c);
+  }
+  v = apply_epilogue<EPI>(v, b, r);
+  float* out = a.out + (size_t)g * a.out_gs;
+  if (OUTF == FMT_SPLIT) {
+    if (store_split4(out, opix, a.out_ld, c, v)) atomicOr(a.overflow, 1);
+  } else {
+    *reinterpret_cast<float4*>(out + opix * a.out_ld + c) = v;
+  }
+}
+
+template <int EPI, int MM, int OUTF, int RESF>
+__global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvArgs a, int cout, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (group, m, c4)
+  if (idx >= total) return;
+  const int q4 = cout >> 2;
+  const int c = (idx % q4) * 4, t = idx / q4;
+  const int g = t / a.M, m = t % a.M;
+  reduce_element<EPI, MM, OUTF, RESF>(a, a.part + ((size_t)g * a.M + m) * cout + c, (size_t)a.groups * a.M * cout, g, m, c);
+}
+
+// The reduction INSIDE the split-K launch (a.sem != nullptr): the grid carries, after the conv workgroups, a.rpt reduce
+// workgroups per output tile (a power of two <= 32: each takes 128 / rpt rows).  A conv workgroup publishes its partial tile (device-scope release) and counts itself into sem[tile];
+// a reduce workgroup sleeps until the count reaches `slices`, then sums its rows of the tile in the same fixed slice order as
+// conv_reduce_kernel -- bitwise the same result, without the second launch.  MEASURED SLOWER (EXPERIMENTS item 41: 363 vs 268 us per
+// batch-1 forward): partial sums that another XCD must see inside the launch have to be written through / read around the per-XCD
+// L2, which costs more than the 5-6 us launch it saves.  Kept behind SE3TN_SPLITK_FUSED=1 with its bitwise A/B check.
+// No deadlock: conv workgroups never wait, and the reduce workgroups (rpt x tiles <= 256) cannot occupy every workgroup
+// slot of the device (launch_splitk checks), whatever order the dispatcher takes.
+template <int MM, int BM, int BN>
+__device__ __forceinline__ void splitk_reduce_part(const ConvArgs& a, int tile, int seg) {
+  const int panels = a.groups * a.tiles_n;
+  const int p = tile % panels, mt = tile / panels;
+  const int g = p / a.tiles_n, nt = p - g * a.tiles_n;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    // (an atomic read-modify-write executes in the XCD's L2, where the conv workgroups' arrivals are counted: no stale L1 line)
+    while (__hip_atomic_fetch_add(a.sem + tile, 0, __ATOMIC_RELAXED, SE3TN_SEM_SCOPE) < a.slices) __builtin_amdgcn_s_sleep(1);
+    // the last reduce workgroup to see the tile complete re-arms both counters for the next launch
+    if (__hip_atomic_fetch_add(a.sem + SE3TN_SPLITK_MAX_TILES + tile, 1, __ATOMIC_RELAXED, SE3TN_SEM_SCOPE) == a.rpt - 1) {
+      __hip_atomic_exchange(a.sem + tile, 0, __ATOMIC_RELAXED, SE3TN_SEM_SCOPE);
+      __hip_atomic_exchange(a.sem + SE3TN_SPLITK_MAX_TILES + tile, 0, __ATOMIC_RELAXED, SE3TN_SEM_SCOPE);
+    }
+  }
+  __syncthreads();
+#if SE3TN_SPLITK_WT
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every thread reads the partial sums other compute units stored
+#else
+  // the partial sums are in THIS XCD's L2 (written by its other compute units): only this compute unit's vector L1 may hold stale
+  // lines of the workspace (an agent-scope acquire would also drop the L2's clean lines under the conv workgroups still running)
+  asm volatile("buffer_inv sc0" ::: "memory");
+#endif
+  // the partial tiles are stored in ACCUMULATOR-FRAGMENT order (conv3x3_splitk_kernel): float4 number
+  //   f = (((wave * PT + i) * CT + j) * 4 + q) * 64 + lane   of tile `tile` of slice s at part[(s * tiles + tile) * BM * BN + 4 f]
+  // -- every store / load instruction of a wave moves one contiguous KB
+  constexpr int PT = 2, CT = BN / 64, E = BM * BN / 4;
+  const int tiles = ((a.M + BM - 1) / BM) * panels;
+  const int per = E / a.rpt;
+  const size_t slice_stride = (size_t)tiles * BM * BN;
+  for (int e = tid; e < per; e += 256) {
+    const int f = seg * per + e;
+    const int lane = f & 63, q = (f >> 6) & 3, t8 = f >> 8;
+    const int j = t8 % CT, i = (t8 / CT) % PT, wv = t8 / (CT * PT);
+    const int m = mt * BM + ((wv >> 1) * PT + i) * 32 + (lane & 31);
+    const int c = nt * BN + ((wv & 1) * CT + j) * 32 + q * 8 + (lane >> 5) * 4;
+    if (m >= a.M) continue;
+    const float* src = a.part + (size_t)tile * BM * BN + (size_t)f * 4;
+    if (MM == MM_F16X3) {
+      if (a.epi == 0) reduce_element<0, MM_F16X3, FMT_SPLIT, FMT_F32>(a, src, slice_stride, g, m, c);
+      else if (a.epi == 2) reduce_element<2, MM_F16X3, FMT_SPLIT, FMT_F32>(a, src, slice_stride, g, m, c);
+      else if (a.outf == FMT_SPLIT) reduce_element<1, MM_F16X3, FMT_SPLIT, FMT_SPLIT>(a, src, slice_stride, g, m, c);
+      else reduce_element<1, MM_F16X3, FMT_F32, FMT_SPLIT>(a, src, slice_stride, g, m, c);
+    } else {
+      if (a.epi == 0) reduce_element<0, MM_F32, FMT_F32, FMT_F32>(a, src, slice_stride, g, m, c);
+      else if (a.epi == 1) reduce_element<1, MM_F32, FMT_F32, FMT_F32>(a, src, slice_stride, g, m, c);
+      else reduce_element<2, MM_F32, FMT_F32, FMT_F32>(a, src, slice_stride, g, m, c);
+    }
+  }
+}
+
 // =================================================================================================
 // small-batch (latency) path: split-K.  At batch 1 the big-tile kernels above would occupy 8-64 of
 // the 256 CUs (M = 121..1936 rows), so the K dimension -- cin / 32 chunks x 9 taps K-steps -- is cut into `slices` runs of
@@ -427,7 +551,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_splitk_kernel(const ConvArgs a
   const int l31 = lane & 31, hh = lane >> 5;
 
   const int panels = a.groups * a.tiles_n;
-  const int sl = blockIdx.x % a.slices, rest = blockIdx.x / a.slices;
+  int sl = blockIdx.x % a.slices, rest = blockIdx.x / a.slices;
+  if (a.sem) {   // (uniform) fused reduction: every workgroup of tile t -- its slices and its reduce workgroups -- has blockIdx = t (mod 8),
+    // i.e. runs on ONE XCD, whose L2 then holds the tile's partial sums; the workgroups behind the conv workgroups reduce
+    const int tiles = ((a.M + BM - 1) / BM) * panels, tg = (tiles + 7) / 8;
+    const int conv_wgs = tg * a.slices * 8;
+    const int b = (int)blockIdx.x;
+    if (b >= conv_wgs) {
+      const int rb = b - conv_wgs, q = rb >> 3;
+      const int t = (q / a.rpt) * 8 + (rb & 7);
+      if (t < tiles) splitk_reduce_part<MM, BM, BN>(a, t, q % a.rpt);
+      return;
+    }
+    const int q = b >> 3;
+    rest = (q / a.slices) * 8 + (b & 7);
+    sl = q % a.slices;
+    if (rest >= tiles) return;
+  }
   const int p = rest % panels, mt = rest / panels;
   const int g = p / a.tiles_n, nt = p % a.tiles_n;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -506,60 +646,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_splitk_kernel(const ConvArgs a
   }
 #undef ISSUE_TILE
 
-  // raw partial sums: part[slice][group][m][cout]
+  // raw partial sums: part[slice][group][m][cout] for conv_reduce_kernel; with the fused reduction, accumulator-fragment order
+  // (splitk_reduce_part), written THROUGH the XCD's L2: another XCD's reduce workgroup reads it in this launch
   const int cout = a.tiles_n * BN;
-  float* __restrict__ part = a.part + ((size_t)(sl * a.groups + g) * a.M) * cout;
+  if (a.sem) {
+    const int tiles = ((a.M + BM - 1) / BM) * panels;
+    float* __restrict__ ptile = a.part + ((size_t)sl * tiles + rest) * (BM * BN);
 #pragma unroll
-  for (int i = 0; i < PT; ++i) {
-    const int m = m0 + (wm * PT + i) * 32 + l31;
-    if (m >= a.M) continue;
+    for (int i = 0; i < PT; ++i)
 #pragma unroll
-    for (int j = 0; j < CT; ++j)
+      for (int j = 0; j < CT; ++j)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = n0 + (wn * CT + j) * 32 + q * 8 + hh * 4;
-        *reinterpret_cast<float4*>(part + (size_t)m * cout + c) =
-            make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-      }
-  }
-}
-
-template <int EPI, int MM, int OUTF, int RESF>
-__global__ __launch_bounds__(256) void conv_reduce_kernel(const ConvArgs a, int cout, int total) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;  // (group, m, c4)
-  if (idx >= total) return;
-  const int q4 = cout >> 2;
-  const int c = (idx % q4) * 4, t = idx / q4;
-  const int m = t % a.M, g = t / a.M;
-  const size_t slice_stride = (size_t)a.groups * a.M * cout;
-  const float* src = a.part + ((size_t)g * a.M + m) * cout + c;
-  float4 v = *reinterpret_cast<const float4*>(src);
-#pragma unroll 8
-  for (int s = 1; s < a.slices; ++s) {  // fixed order: deterministic (unrolled: the loads of 8 slices are in flight together)
-    const float4 u = *reinterpret_cast<const float4*>(src + s * slice_stride);
-    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-  }
-  if (MM == MM_F16X3) {
-    const float4 w = *reinterpret_cast<const float4*>(a.wscale + (size_t)g * a.bias_gs + c);
-    v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
-  }
-  const size_t opix = (size_t)padded_index(m, a.Ho * a.Wo, a.Wo);
-  const float4 b = *reinterpret_cast<const float4*>(a.bias + (size_t)g * a.bias_gs + c);
-  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (EPI == 1) {
-    const float* res = a.res + (size_t)g * a.res_gs;
-    r = (RESF == FMT_SPLIT) ? load_split4(res, opix, a.res_ld, c) : *reinterpret_cast<const float4*>(res + opix * a.res_ld + c);
-  }
-  v = apply_epilogue<EPI>(v, b, r);
-  float* out = a.out + (size_t)g * a.out_gs;
-  if (OUTF == FMT_SPLIT) {
-    if (store_split4(out, opix, a.out_ld, c, v)) atomicOr(a.overflow, 1);
+        for (int q = 0; q < 4; ++q)
+          store_partial(ptile + (size_t)(((((wid * PT + i) * CT + j) * 4 + q) * 64 + lane) * 4),
+                        make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]));
   } else {
-    *reinterpret_cast<float4*>(out + opix * a.out_ld + c) = v;
+    float* __restrict__ part = a.part + ((size_t)(sl * a.groups + g) * a.M) * cout;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int m = m0 + (wm * PT + i) * 32 + l31;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = n0 + (wn * CT + j) * 32 + q * 8 + hh * 4;
+          *reinterpret_cast<float4*>(part + (size_t)m * cout + c) =
+              make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        }
+    }
+  }
+  if (a.sem) {   // publish: the stores have been acknowledged by the device-coherent level, then ONE arrival per workgroup.
+    // (A release fence per thread -- __threadfence() -- writes the whole L2 back 256 times per workgroup: 864 us per forward
+    // instead of 268, measured.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.sem + rest, 1, __ATOMIC_RELAXED, SE3TN_SEM_SCOPE);
   }
 }
 
-// ---- launchers ---------------------------------------------------------------------------------
 template <typename K>
 static hipError_t set_lds(K kern, size_t lds, PerDeviceOnce& once) {
   bool* done = once.current();
@@ -617,17 +742,35 @@ static void launch_reduce(const ConvArgs& a, int cout, hipStream_t st) {
   hipLaunchKernelGGL((conv_reduce_kernel<EPI, MM, OUTF, RESF>), dim3((total + 255) / 256), dim3(256), 0, st, a, cout, total);
 }
 
+// the fused reduction's reduce workgroups: at most this many per launch (the launch holds 512 workgroup slots: 2 per compute unit)
+#ifndef SE3TN_SPLITK_MAX_REDUCE_WGS
+#define SE3TN_SPLITK_MAX_REDUCE_WGS 256
+#endif
 // outf / resf: FMT_* of the output and residual tensors (f16x3 mode: split rows except the last head conv)
 template <int CIN, int STRIDE, int CT, int MM>
-static hipError_t launch_splitk(const ConvArgs& a, int epi, int outf, int resf, hipStream_t st) {
+static hipError_t launch_splitk(const ConvArgs& a0, int epi, int outf, int resf, hipStream_t st) {
   constexpr int BN = 64 * CT;
   constexpr size_t lds = (size_t)2 * (128 + BN) * 32 * sizeof(float);
   auto kern = conv3x3_splitk_kernel<CIN, STRIDE, CT, MM>;
   static PerDeviceOnce attr;
   hipError_t e = set_lds(kern, lds, attr);
   if (e != hipSuccess) return e;
-  const int tiles_m = (a.M + 127) / 128;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * a.tiles_n * a.groups * a.slices), dim3(256), lds, st, a);
+  const int tiles_m = (a0.M + 127) / 128;
+  const int tiles = tiles_m * a0.tiles_n * a0.groups;
+  if (a0.sem && tiles <= SE3TN_SPLITK_MAX_TILES && tiles * 4 <= SE3TN_SPLITK_MAX_REDUCE_WGS &&
+      (size_t)a0.slices * tiles * 128 * BN * sizeof(float) <= a0.part_bytes) {
+    // reduction inside this launch: rpt reduce workgroups per tile, ~128 in all (few tiles: more, thinner row bands)
+    ConvArgs a = a0;
+    int rpt = 4;
+    while (rpt < 32 && tiles * rpt * 2 <= SE3TN_SPLITK_MAX_REDUCE_WGS / 2) rpt *= 2;
+    a.rpt = rpt; a.epi = epi; a.outf = outf; a.resf = resf;
+    const int tg = (tiles + 7) / 8;
+    hipLaunchKernelGGL(kern, dim3(tg * 8 * (a.slices + rpt)), dim3(256), lds, st, a);
+    return hipGetLastError();
+  }
+  ConvArgs a = a0;
+  a.sem = nullptr;
+  hipLaunchKernelGGL(kern, dim3(tiles * a.slices), dim3(256), lds, st, a);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int cout = a.tiles_n * BN;

@@ -100,8 +100,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const CropArgs a) {
   o.y = (float)(((double)g - mean[1]) / sd[1]);
   o.z = (float)(((double)b - mean[2]) / sd[2]);
   o.w = (float)(((double)d - mean[3]) / sd[3]);
-  float* dst = a.padded ? a.out + (((size_t)i * IN_P + y + IN_PAD) * IN_P + x + IN_PAD) * 4
-                        : a.out + ((size_t)i * RES * RES + p) * 4;
+  float* base = i < a.n_first ? a.out : a.out2;
+  const int io = i < a.n_first ? i : i - a.n_first;
+  float* dst = a.padded ? base + (((size_t)io * IN_P + y + IN_PAD) * IN_P + x + IN_PAD) * 4
+                        : base + ((size_t)io * RES * RES + p) * 4;
   if (a.split) {
     bool bad = false;
     o = split_pixel(o, bad);
@@ -154,57 +156,71 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ head,
-                                                   const float* __restrict__ fc_w,
-                                                   const float* __restrict__ fc_b,
-                                                   float* __restrict__ logits, float* __restrict__ trans,
-                                                   float* __restrict__ rot, const double* __restrict__ poseA,
-                                                   double* __restrict__ poseB, double tn, double rn) {
+// 1024 threads: thread (grp, t) sums pixels [grp * 43, grp * 43 + 43) of channels 4t..4t+3 (43 loads, 11 in flight: the loop is a
+// latency chain -- one workgroup of 256 threads walking all 169 padded pixels took 11.8 us at batch 1), the four partial sums are
+// added in a fixed order
+__global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ head,
+                                                    const float* __restrict__ fc_w,
+                                                    const float* __restrict__ fc_b,
+                                                    float* __restrict__ logits, float* __restrict__ trans,
+                                                    float* __restrict__ rot, const double* __restrict__ poseA,
+                                                    double* __restrict__ poseB, double tn, double rn) {
   __shared__ float part[4][3];
   __shared__ float outv[6];
-  const int n = blockIdx.x, t = threadIdx.x;
-  constexpr int PP = (S4 + 2) * (S4 + 2);
+  __shared__ float4 psum[3][256];
+  const int n = blockIdx.x, t = threadIdx.x & 255, grp = threadIdx.x >> 8;
+  constexpr int PP = (S4 + 2) * (S4 + 2), PG = (PP + 3) / 4;
   const float* src = head + (size_t)n * PP * 1024 + t * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   // History (profiles/EXPERIMENTS.md items 13): for this loop hipcc once kept the (x, y) sums swapped in their register pair and added
   // with `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]`; on gfx950 that form returns wrong lanes 48-63 while another kernel's waves
   // issue v_mfma_f32_32x32x16_f16 on the same CU (two f16x3 contexts in flight: wrong sums in 40-85 % of the launches).  The device
   // code is therefore compiled without packed-float32 instructions (Makefile), and scripts/isa_lint.py checks the library for the form.
-#pragma unroll 13
-  for (int p = 0; p < PP; ++p) {
+  const int p_end = min(PP, (grp + 1) * PG);
+#pragma unroll 11
+  for (int p = grp * PG; p < p_end; ++p) {
     const float4 v = *reinterpret_cast<const float4*>(src + (size_t)p * 1024);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
-  const float inv = (float)(S4 * S4);
-  s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv;
-  const int hd = t >> 7;            // 0 trans, 1 rot
-  const int cl = (t & 127) * 4;     // channel within the head
-  float acc[3];
-#pragma unroll
-  for (int o = 0; o < 3; ++o) {
-    const float4 w = *reinterpret_cast<const float4*>(fc_w + (hd * 3 + o) * 512 + cl);
-    acc[o] = wave_sum(s.x * w.x + s.y * w.y + s.z * w.z + s.w * w.w);
-  }
-  if ((t & 63) == 0) { part[t >> 6][0] = acc[0]; part[t >> 6][1] = acc[1]; part[t >> 6][2] = acc[2]; }
+  if (grp > 0) psum[grp - 1][t] = s;
   __syncthreads();
-  if (t < 6) {
-    const int h = t / 3, o = t - h * 3;
+  if (grp == 0) {   // (whole waves: a group is four of the sixteen)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 v = psum[k][t];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float inv = (float)(S4 * S4);
+    s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv;
+    const int hd = t >> 7;            // 0 trans, 1 rot
+    const int cl = (t & 127) * 4;     // channel within the head
+    float acc[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const float4 w = *reinterpret_cast<const float4*>(fc_w + (hd * 3 + o) * 512 + cl);
+      acc[o] = wave_sum(s.x * w.x + s.y * w.y + s.z * w.z + s.w * w.w);
+    }
+    if ((t & 63) == 0) { part[t >> 6][0] = acc[0]; part[t >> 6][1] = acc[1]; part[t >> 6][2] = acc[2]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x, h = k / 3, o = k - h * 3;
     const float lg = part[2 * h][o] + part[2 * h + 1][o] + fc_b[h * 4 + o];
     const float y = tanhf(lg);
-    logits[n * 6 + t] = lg;
-    outv[t] = y;
+    logits[n * 6 + k] = lg;
+    outv[k] = y;
     if (h == 0) { if (trans) trans[n * 3 + o] = y; }
     else        { if (rot) rot[n * 3 + o] = y; }
   }
   if (poseA == nullptr) return;
   __syncthreads();
-  if (t == 0) pose_compose(outv, poseA + (size_t)n * 16, poseB + (size_t)n * 16, tn, rn);
+  if (threadIdx.x == 0) pose_compose(outv, poseA + (size_t)n * 16, poseB + (size_t)n * 16, tn, rn);
 }
 
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,
                        double rn, int n, hipStream_t st) {
-  hipLaunchKernelGGL(tail_kernel, dim3(n), dim3(256), 0, st, head, fc_w, fc_b, logits, trans, rot,
+  hipLaunchKernelGGL(tail_kernel, dim3(n), dim3(1024), 0, st, head, fc_w, fc_b, logits, trans, rot,
                      poseA, poseB, tn, rn);
   return hipGetLastError();
 }

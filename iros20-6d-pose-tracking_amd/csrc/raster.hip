@@ -29,18 +29,21 @@
 // linearised to camera z.  Coverage, depth and vertex colours follow the same rules exactly; the texture FILTER is float32
 // arithmetic here (the GL implementation filters in 16-bit fixed point): textured colours agree to a few / 255.
 //
-// Kernels: vertices -> clip / window space; one thread per triangle scatters (z | triangle id) keys (large bounding boxes: one wave
-// per triangle, raster_big_kernel; triangles crossing the frustum: one wave clips and walks the outline, raster_clip_kernel); one
-// thread per pixel re-derives the plane equations of the winning triangle, interpolates and shades.
+// Four launches: vertices -> clip / window space (+ z-buffer / queue clears); one thread per triangle scatters (z | triangle id) keys;
+// raster_queue_kernel: large bounding boxes by one wave per triangle, triangles crossing the frustum clipped and their outline walked
+// by one wave; one thread per pixel re-derives the plane equations of the winning triangle, interpolates and shades.
 #include "se3tn_internal.h"
 
 namespace se3tn {
 
-constexpr int RASTER_BIG_PX = 256;   // bounding boxes above this many pixels go to raster_big_kernel
+constexpr int RASTER_BIG_PX = 256;   // bounding boxes above this many pixels go to the wave-per-triangle path of raster_queue_kernel
 constexpr int CLIP_RIGHT = 1, CLIP_TOP = 2, CLIP_FAR = 4, CLIP_LEFT = 8, CLIP_BOTTOM = 16, CLIP_NEAR = 32;
 
 __global__ __launch_bounds__(256) void raster_vertex_kernel(const RasterArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  // this launch also clears the z-buffer and the two queue counters (they are first touched by the NEXT launch)
+  for (int p = i; p < a.rw * a.rh; p += gridDim.x * 256) a.zbuf[p] = ~0ull;
+  if (i == 0) { a.big[0] = 0; a.clipq[0] = 0; }
   if (i >= a.V) return;
   const float px = a.verts[3 * i], py = a.verts[3 * i + 1], pz = a.verts[3 * i + 2];
   float c[4];
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void raster_triangle_kernel(const RasterArgs a
   bool d;
   const int kind = tri_load(a, t, post, snap, d);
   if (kind == 0) return;
-  if (kind == 2) {   // crosses the frustum: clipped and walked by a whole wave (raster_clip_kernel)
+  if (kind == 2) {   // crosses the frustum: clipped and walked by a whole wave (raster_queue_kernel)
     const int k = atomicAdd(a.clipq, 1);
     a.clipq[1 + k] = t;
     return;
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256) void raster_triangle_kernel(const RasterArgs a
   Edges e;
   if (!edges_setup(a, snap, d, e)) return;
   // a triangle that covers many pixels (coarse mesh, close-up) would serialise this thread: it is queued for
-  // raster_big_kernel, where a whole wave walks its bounding box.  The z-buffer keys make the result independent of
+  // raster_queue_kernel, where a whole wave walks its bounding box.  The z-buffer keys make the result independent of
   // the order in which the queue is filled.
   if ((e.x1 - e.x0) * (e.y1 - e.y0) > RASTER_BIG_PX) {
     const int k = atomicAdd(a.big, 1);
@@ -236,9 +239,10 @@ __global__ __launch_bounds__(256) void raster_triangle_kernel(const RasterArgs a
 }
 
 // one wave per queued triangle, lanes stride over the pixels of its bounding box
-__global__ __launch_bounds__(256) void raster_big_kernel(const RasterArgs a) {
+constexpr int BIG_BLOCKS = 128, CLIP_BLOCKS = 64;   // raster_queue_kernel: blocks [0, 128) walk the big-triangle queue, the rest clip
+__device__ __forceinline__ void raster_big_part(const RasterArgs& a) {
   const int nbig = a.big[0];
-  const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (BIG_BLOCKS * 256) >> 6;
   for (int k = wave; k < nbig; k += nwaves) {
     const int t = a.big[1 + k];
     float4 post[3];
@@ -286,16 +290,21 @@ __device__ __forceinline__ void plane_exact(float4& b, int plane) {
 
 constexpr int CLIP_MAX_ROWS = 2048;   // frame heights the outline tables hold (se3tn_render_frame checks)
 
-// one 64-thread workgroup (= one wave) per queued triangle: lane 0 clips the triangle to a polygon and snaps it, the wave
+// one wave (the first of a clip block of raster_queue_kernel) per queued triangle: lane 0 clips the triangle to a polygon and snaps it, the wave
 // walks the polygon's edges IN ORDER (a later edge overwrites an earlier one on a shared row, as the span tables of the
 // implementation do), then rasterises the rows of the outline
-__global__ __launch_bounds__(64) void raster_clip_kernel(const RasterArgs a) {
+__global__ __launch_bounds__(256) void raster_queue_kernel(const RasterArgs a) {
   __shared__ int tab[2][CLIP_MAX_ROWS];   // [0] left, [1] right
   __shared__ int PX[12], PY[12], pn;
+  if (blockIdx.x < BIG_BLOCKS) {
+    raster_big_part(a);
+    return;
+  }
   const int nq = a.clipq[0];
+  if (nq == 0 || threadIdx.x >= 64) return;   // the clip blocks work with their first wave (barriers count live waves only)
   const int lane = threadIdx.x;
   const int sb = a.sub_bits;
-  for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+  for (int q = blockIdx.x - BIG_BLOCKS; q < nq; q += CLIP_BLOCKS) {
     const int t = a.clipq[1 + q];
     float4 post[3];
     int4 snap[3];
@@ -523,16 +532,12 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const RasterArgs a)
 }
 
 hipError_t launch_raster(const RasterArgs& a, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(a.zbuf, 0xff, sizeof(unsigned long long) * a.rw * a.rh, st);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(raster_vertex_kernel, dim3((a.V + 255) / 256), dim3(256), 0, st, a);
-  e = hipMemsetAsync(a.big, 0, sizeof(int), st);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(a.clipq, 0, sizeof(int), st);
-  if (e != hipSuccess) return e;
+  // one thread per vertex; the z-buffer clear strides over the grid (at least 128 blocks, or one per 256 pixels if that is fewer)
+  const int vb = (a.V + 255) / 256, zb = (a.rw * a.rh + 255) / 256;
+  const int clear_blocks = zb < 128 ? zb : 128;
+  hipLaunchKernelGGL(raster_vertex_kernel, dim3(vb > clear_blocks ? vb : clear_blocks), dim3(256), 0, st, a);
   hipLaunchKernelGGL(raster_triangle_kernel, dim3((a.F + 255) / 256), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(raster_big_kernel, dim3(128), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(raster_clip_kernel, dim3(256), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(raster_queue_kernel, dim3(BIG_BLOCKS + CLIP_BLOCKS), dim3(256), 0, st, a);
   hipLaunchKernelGGL(raster_resolve_kernel, dim3((a.rw * a.rh + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }

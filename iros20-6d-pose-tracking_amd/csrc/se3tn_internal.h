@@ -131,6 +131,7 @@ constexpr int PAD_SLACK_PX = 8;
 constexpr int IN_PAD = 3;
 constexpr int IN_P = RES + 2 * IN_PAD;  // 182
 constexpr int IN_SLACK_ROWS = 6;
+constexpr int SE3TN_SPLITK_MAX_TILES = 1024;   // output tiles (m tile x group x n tile) of a split-K launch with the fused reduction
 struct ConvArgs {
   const float* in;    // padded NHWC, `in_ld` floats per pixel; channel offset already applied
   const float* w;     // packed panels of group 0
@@ -148,6 +149,11 @@ struct ConvArgs {
   float* part;
   size_t part_bytes;
   int slices;
+  // fused reduction of the split-K path: sem[tile] counts the slices of an output tile that have stored their partial sums,
+  // sem[SE3TN_SPLITK_MAX_TILES + tile] the reduce workgroups that have seen it complete (both are zero between launches).
+  // nullptr = separate conv_reduce_kernel launch.  epi / outf / resf: the epilogue the in-kernel reduction applies
+  int* sem;
+  int epi, outf, resf, rpt;   // rpt: reduce workgroups per output tile
   // f16x3 mode: per-cout power-of-two weight scale (acc * wscale = true sum), overflow flag,
   // fast = 0 (f32 everywhere) | 1 | 2 (see launch_conv3x3)
   const float* wscale;
@@ -199,6 +205,8 @@ struct CropArgs {  // one launch handles up to MAX crops
   se3tn_crop c[MAX];
   double mean[8], stdv[8];
   float* out;   // plain [n,176,176,4], or (padded != 0) the interior of [n,182,182,4]
+  float* out2;  // crops n_first.. go here, numbered from 0 (image A and image B of a frame in ONE launch: se3tn_on_track); else unused
+  int n_first;  // (n when out2 is unused)
   int n;
   int padded;
   int split;    // f16x3 mode: a pixel is stored as 4 x f16 hi | 4 x f16 lo (same 16 bytes)

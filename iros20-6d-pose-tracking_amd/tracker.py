@@ -97,6 +97,7 @@ class Tracker:
         self.prev_rgb = None
         self.prev_depth = None
         self.frame_cnt = 0
+        self.one_call = True     # on_track through se3tn_on_track when the built-in rasteriser renders image A (False: step by step)
         self.errs = []
         dev = "cuda:%d" % device
         self._dev = dev
@@ -162,9 +163,11 @@ class Tracker:
             with torch.cuda.stream(self._stream):
                 return self.on_track(prev_pose, current_rgb, current_depth, gt_A_in_cam, gt_B_in_cam, debug, samples)
         prev_pose = np.asarray(prev_pose, np.float64)
+        from .renderer import HipRenderer
+        if self.one_call and isinstance(self.renderer, HipRenderer) and not self.renderer.full_frame and int(samples) <= 1:
+            return self._on_track_one_call(prev_pose, current_rgb, current_depth)
         bb = U.compute_bbox(prev_pose, self.K, self.object_width, scale=(1000, 1000, 1000))
         dev = self._dev
-        from .renderer import HipRenderer
         winA = (0, 0, self.image_size[0], self.image_size[0])
         if isinstance(self.renderer, HipRenderer) and self.renderer.full_frame:
             # pyrender route: the full rendered frame stays on the device and is cropped by the same kernel (and the
@@ -197,6 +200,35 @@ class Tracker:
         self.prev_depth = current_depth
         self.frame_cnt += 1
         return poseB[0]
+
+    def _on_track_one_call(self, prev_pose, current_rgb, current_depth):
+        """The whole frame in ONE library call (se3tn_on_track): compute_bbox, image A, both crops in one launch, network, pose
+        update, read-back; the camera frame goes up as the window's rows / columns only, through pinned memory, together with the
+        pose.  Same arithmetic as the step-by-step path below (tests/test_tracker_surface.py compares the two)."""
+        import ctypes as C
+        rgb = np.ascontiguousarray(current_rgb, dtype=np.uint8)
+        dep = _depth_u16(current_depth, rgb)
+        if rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise ValueError("rgb must be HxWx3 uint8")
+        P = np.ascontiguousarray(prev_pose, np.float64)
+        K = np.ascontiguousarray(self.K, np.float64)
+        pose = np.empty((4, 4), np.float64)
+        tr = np.empty(3, np.float32); ro = np.empty(3, np.float32)
+        bb = np.empty((4, 2), np.int32)
+        r = self.renderer
+        from ._lib import check
+        from .engine import _stream_ptr
+        check(self.engine.lib.se3tn_on_track(
+            self.engine._h, r._m, P.ctypes.data_as(C.POINTER(C.c_double)), K.ctypes.data_as(C.POINTER(C.c_double)),
+            C.c_double(float(self.object_width)), C.c_void_p(rgb.ctypes.data), C.c_void_p(dep.ctypes.data), int(rgb.shape[0]),
+            int(rgb.shape[1]), C.c_void_p(r.rgb.data_ptr()), C.c_void_p(r.depth.data_ptr()), pose.ctypes.data_as(C.POINTER(C.c_double)),
+            tr.ctypes.data_as(C.POINTER(C.c_float)), ro.ctypes.data_as(C.POINTER(C.c_float)), bb.ctypes.data_as(C.POINTER(C.c_int32)),
+            _stream_ptr()), "se3tn_on_track")
+        self.last_prediction = dict(trans=tr.reshape(1, 3), rot=ro.reshape(1, 3), bbox=bb)
+        self.prev_rgb = current_rgb
+        self.prev_depth = current_depth
+        self.frame_cnt += 1
+        return pose
 
     def on_track_batch(self, prev_poses, rgbs, depths):
         """Extension: n independent (pose, frame) pairs of the SAME object in one engine call -- several

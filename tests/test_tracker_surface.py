@@ -207,3 +207,34 @@ def test_samples_beyond_capacity_and_depth_dtypes(se3, tracker):
         assert (trk.on_track(P, rgb, depth.astype(dt)) == ref).all(), dt
     with pytest.raises(ValueError):
         trk.on_track(P, rgb, depth[:-1])
+
+
+@pytest.mark.gpu
+def test_one_call_on_track_equals_the_step_by_step_path(se3):
+    """se3tn_on_track (one library call per frame: only the window's rows / columns of the frame are uploaded, image A and image B
+    cropped in one launch) against render -> preprocess x 2 -> infer -> read-back: every output bit, for windows inside the
+    frame, leaving it on each side, and missing it entirely."""
+    from oracle import fixtures as Fx
+    from oracle import se3_oracle as O
+    mean, std = Fx.mean_std(0)
+    sd = {"state_dict": O.make_state_dict(0, head_gain=0.01)}
+    trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=150.0), mean, std, sd)
+    trk.renderer = se3.HipRenderer(trk.engine, Fx.icosphere(3, 0.06, 1))
+    rgb, depth = Fx.structured_frame(11)
+    cases = [(0.02, -0.01, 0.8), (-0.22, 0.0, 0.8), (0.22, 0.05, 0.8), (0.0, -0.17, 0.8), (0.0, 0.17, 0.8), (0.0, 0.0, 0.35),
+             (0.9, 0.9, 0.8), (-0.9, -0.7, 0.8)]
+    for k, t in enumerate(cases):
+        P = Fx.pose(20 + k, t)
+        trk.one_call = True
+        q1 = trk.on_track(P, rgb, depth)
+        p1 = {kk: np.array(v) for kk, v in trk.last_prediction.items()}
+        a1 = (trk.renderer.rgb.cpu().numpy().copy(), trk.renderer.depth.cpu().numpy().copy())
+        l1 = trk.engine.logits(1).cpu().numpy().copy()
+        trk.one_call = False
+        q2 = trk.on_track(P, rgb, depth.astype(np.int32))                      # (and a wider depth dtype on this side)
+        p2 = trk.last_prediction
+        assert np.array_equal(q1, q2), (t, np.abs(q1 - q2).max())
+        assert np.array_equal(p1["trans"], p2["trans"]) and np.array_equal(p1["rot"], p2["rot"]) and np.array_equal(p1["bbox"], p2["bbox"])
+        assert np.array_equal(a1[0], trk.renderer.rgb.cpu().numpy()) and np.array_equal(a1[1], trk.renderer.depth.cpu().numpy())
+        assert np.array_equal(l1, trk.engine.logits(1).cpu().numpy())
+    assert trk.frame_cnt == 2 * len(cases)
