@@ -640,7 +640,13 @@ def main():
         if direct is not None:
             out["alt_algorithm"] = direct
         prof = pmc_traffic(nb)
-        if prof is not None:
+        # the committed PMC passes are of the DEFAULT float32 configuration: another precision / algorithm setting keeps traffic null
+        #  and carries the profile only as `traffic_from_profile`
+        default_cfg = (args.precision == "f32" and args.winograd is None and args.winograd_tile == 0 and args.stage == "full"
+                       and not any(k.startswith(("SE3TN_WINO", "SE3TN_TRUNK", "SE3TN_SPLITK", "SE3TN_GEMM")) for k in os.environ))
+        if prof is not None and not default_cfg:
+            out["roofline"]["traffic_from_profile"] = dict(prof, note=prof["note"] + "; NOT this run's configuration")
+        elif prof is not None:
             # PMC counters need rocprofv3 around the process, so the line quotes the newest COMMITTED profile of this command (per step
             # of the conv family, FETCH_SIZE x 2 + WRITE_SIZE) and says so; `traffic_from_profile` has the details
             out["roofline"]["traffic"] = prof["bytes_per_step"]

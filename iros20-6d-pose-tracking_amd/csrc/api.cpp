@@ -436,7 +436,8 @@ const void* se3tn_packed_host(const se3tn_ctx* c) { return (c && !c->packed.empt
 int se3tn_upload_weights(se3tn_ctx* c, void* stream) {
   if (!c || c->device < 0) return fail(SE3TN_E_ARG, "se3tn_upload_weights: no device context");
   if (c->packed.empty()) return fail(SE3TN_E_STATE, "se3tn_upload_weights: call se3tn_pack_weights first");
-  HIPCHK(hipSetDevice(c->device));
+  DeviceGuard dg(c->device);   // init-time entry point: runs on the context's device, leaves the caller's current device alone
+  HIPCHK(dg.err);
   if (!c->blob_owned) HIPCHK(hipMalloc((void**)&c->blob_owned, c->L.total * sizeof(float)));
   HIPCHK(hipMemcpyAsync(c->blob_owned, c->packed.data(), c->L.total * sizeof(float), hipMemcpyHostToDevice,
                         (hipStream_t)stream));
@@ -534,7 +535,8 @@ int se3tn_set_precision(se3tn_ctx* c, int mode) {
 
 int se3tn_reserve(se3tn_ctx* c, int H, int W) {
   if (!c || c->device < 0 || H < 1 || W < 1) return fail(SE3TN_E_ARG, "se3tn_reserve: bad argument");
-  HIPCHK(hipSetDevice(c->device));
+  DeviceGuard dg(c->device);
+  HIPCHK(dg.err);
   if (int rc = reserve_fill_depth(c, (size_t)H * W)) return rc;
   if (int rc = reserve_zbuf(c, (size_t)H * W)) return rc;
   if (int rc = wino_prepare(c, nullptr)) return rc;

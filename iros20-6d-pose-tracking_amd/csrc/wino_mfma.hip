@@ -1141,7 +1141,11 @@ static hipError_t launch_gemm_auto(const WinoArgs& a, hipStream_t st) {
   if (SE3TN_WINO_GEMMP && a.gemmp != 0 && a.Cout % 256 == 0 && (a.groups * a.nf) % 8 == 0) {
     const int cus = a.num_cus > 0 ? a.num_cus : 256;
     const int tiles = (a.Cout / 256) * ((a.T + 127) / 128) * a.groups * a.nf;
-    if (a.gemmp == 1 || tiles >= 2 * cus) return launch_gemmp<CIN>(a, tiles, tiles < cus ? tiles : (cus / 8) * 8, st);
+    // the automatic rule takes it for the plane sets it was measured on (EXPERIMENTS item 27): F(6x6).  The two-group F(4x4) heads
+    // (72 planes, T = 576 at batch 64 = 4.5 row tiles) also pass the divisibility test above and would trade their exact-fit 96-row
+    // tiling for it unmeasured: they keep launch_gemm unless gemmp == 1 forces it.
+    const bool measured_shape = a.nf == 64;
+    if (a.gemmp == 1 || (tiles >= 2 * cus && measured_shape)) return launch_gemmp<CIN>(a, tiles, tiles < cus ? tiles : (cus / 8) * 8, st);
   }
   if (SE3TN_WINO_GEMM8 && q96 < q128) return launch_gemm8<CIN>(a, st);
   return q96 < q128 ? launch_gemm<CIN, 1, 4, 3, 1>(a, st) : launch_gemm<CIN, 2, 2, 2, 2>(a, st);

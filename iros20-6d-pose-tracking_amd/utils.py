@@ -244,6 +244,10 @@ def _obj_geometry_fast(lines):
     ndb = np.fromiter((r.count("//") for r in fl), dtype=np.int64, count=len(fl))
     if not (nsl == 3 * nslash).all() or not (ndb == (3 if double else 0)).all():
         return None
+    # ... and per TOKEN: "1/4 2/3/1 4" has 3 tokens and 3 slashes like "1/4 2/3 4/1" (ADVICE r4); only when a line's count
+    # matches are its tokens looked at one by one
+    if nslash and any(t.count("/") != nslash or ("//" in t) != double for r in fl for t in r.split()):
+        return None
     joined = " ".join(fl)
     if double:
         joined = joined.replace("//", "/0/")

@@ -164,6 +164,10 @@ def test_obj_fast_parser_equals_general_parser(U, tmp_path):
         got, want = U.load_obj_mesh(str(tmp_path / "mix.obj")), U._load_obj_geometry_general(lines)
         for k in ("vertices", "faces", "colors"):
             assert np.array_equal(got[k], want[k]), (body, k)
+    # corner formats mixed INSIDE one face line: 3 tokens, 3 slashes, 6 integers like "1/3 2/2 1/4" 
+    mixed = (tri + "f 1/3 2/2/1 4\n").splitlines()
+    assert U._obj_geometry_fast(mixed) is None
+    assert U._load_obj_geometry_general(mixed)["faces"].shape == (1, 3)
     assert U._obj_geometry_fast((tri + "f 1/1 2/2 3/3\nf 1 2 3 4 5 6\n").splitlines()) is None
     assert U._obj_geometry_fast((tri + "f 1/1/1 2/2/2 3/3/3\nf 1//1 2//2 3//3\n").splitlines()) is None
     (tmp_path / "vc.obj").write_text("v 0 0 0 1 0 0\nv 1 0 0 0 1 0\nv 1 1 0 0 0 1\nf 1 2 3\n")
