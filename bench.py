@@ -653,6 +653,9 @@ def main():
             out["roofline"]["traffic_unit"] = "bytes per step (conv family), HBM + Infinity Cache"
             out["roofline"]["traffic_source"] = prof["source"] + " (committed rocprofv3 PMC passes of this command; not measured by this run)"
             out["roofline"]["traffic_from_profile"] = prof
+            # per-kernel matrix-core occupancy of the same committed PMC passes beside the per-launch table
+            out["roofline"]["mfma_busy_by_kernel"] = prof.get("mfma_busy_by_kernel", {})
+            out["roofline"]["mfma_busy_source"] = prof["source"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(O, sd, nb, oracle_inputs)
         if world == 1 and args.track_frames > 0 and args.precision == "f32":
@@ -809,7 +812,14 @@ def pmc_traffic(nb):
                 bench_value = json.load(open(bfile)).get("value")
             except Exception:   # noqa: BLE001
                 bench_value = None
+        # MFMA-busy per kernel from the SQ pass of the same profile: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
+        busy = {}
+        for kname, cnt in (d.get("sq") or {}).items():
+            gui, mf = cnt.get("GRBM_GUI_ACTIVE", 0), cnt.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
+            if gui and mf and kname in ps.get("launches_per_step", {}):
+                busy[kname] = round(mf / (gui / 8 * 1024), 4)
         return {"bytes_per_step": int(ps["conv_family_bytes"]), "all_kernels_bytes_per_step": int(ps["all_kernels_bytes"]),
+                "mfma_busy_by_kernel": busy,
                 "source": "profiles/%s_pmc.json" % tag, "profile_bench_value": bench_value,
                 "algorithmic_bytes_per_step": nb * 991256 + 54100000,
                 "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE passes of a committed earlier run of this "

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -101,7 +102,9 @@ struct se3tn_ctx {
   int raster_sub_bits = 4;                      // se3tn_set_raster_rule: sub-pixel bits of the rasteriser's window coordinates
   // se3tn_on_track: pinned host staging [pose 128 B | frame window rgb | depth], its device mirror, device outputs and their pinned copy
   uint8_t* trk_host = nullptr; uint8_t* trk_dev = nullptr; size_t trk_bytes = 0;
-  uint8_t* trk_out_dev = nullptr; uint8_t* trk_out_host = nullptr;
+  uint8_t* trk_out_dev = nullptr; uint8_t* trk_out_host = nullptr;   // ONE mapped pinned block: device address | host address
+  int* tail_flag = nullptr; int tail_seq = 0;   // set around se3tn_on_track's infer: the tail kernel stores tail_seq to this (mapped) word
+  hipStream_t trk_copy_stream = nullptr; hipEvent_t trk_copy_event = nullptr;
   uint8_t* trk_rgbA = nullptr; uint16_t* trk_depthA = nullptr;
   int in_split[2] = {0, 0};                     // pixel format currently held by inA / inB
   bool last_fast = false;                       // the last infer ran the f16x3 kernels (ab is split rows)
@@ -392,7 +395,9 @@ void se3tn_destroy(se3tn_ctx* c) {
     if (c->overflow) (void)hipFree(c->overflow);
     if (c->trk_host) (void)hipHostFree(c->trk_host);
     if (c->trk_out_host) (void)hipHostFree(c->trk_out_host);
-    for (void* b : {(void*)c->trk_dev, (void*)c->trk_out_dev, (void*)c->trk_rgbA, (void*)c->trk_depthA})
+    if (c->trk_copy_event) (void)hipEventDestroy(c->trk_copy_event);
+    if (c->trk_copy_stream) (void)hipStreamDestroy(c->trk_copy_stream);
+    for (void* b : {(void*)c->trk_dev, (void*)c->trk_rgbA, (void*)c->trk_depthA})
       if (b) (void)hipFree(b);
     if (c->zbuf) (void)hipFree(c->zbuf);
     if (c->fd_buf) (void)hipFree(c->fd_buf);
@@ -751,7 +756,9 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
   HIPCHK((hipError_t)prof_mark(c, st, "stem7x7_mfma", false));
   const bool fast = c->prec == SE3TN_PREC_F16X3;  // both the big-tile and the split-K kernels
   c->last_fast = fast;
+#if !defined(SE3TN_ABLATE_POOL)   // (timing-only variant build: what the step costs WITHOUT the pool pass -- EXPERIMENTS item 43)
   HIPCHK(launch_maxpool(c->stem, c->pool, n, fast ? 1 : 0, st));
+#endif
   HIPCHK((hipError_t)prof_mark(c, st, "maxpool3x3s2", false));
 
   auto conv = [&](ConvId id, const float* in, int in_ld, int in_gs, const float* res, int res_ld, int res_gs,
@@ -871,7 +878,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
     float* head_out = fast ? c->head_f : c->head;
     if ((rc = conv(LH2_2, c->head_t, 1024, 512, c->head, 1024, 512, head_out, 1024, 512, S4, 1, 1, "trans|rot conv2.conv2"))) return rc;
     c->head_final = head_out;
-    HIPCHK(launch_tail(head_out, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st));
+    HIPCHK(launch_tail(head_out, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st, c->tail_flag, c->tail_seq));
     HIPCHK((hipError_t)prof_mark(c, st, "tail avgpool+fc+tanh+pose", false));
   }
   if (c->prof) c->slot_launches[slot] = c->n_launch;
@@ -1082,6 +1089,11 @@ int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], cons
     return fail(SE3TN_E_ARG, "se3tn_on_track: bad argument");
   if (!c->have_norm) return fail(SE3TN_E_STATE, "se3tn_on_track: call se3tn_set_normalization first");
   hipStream_t st = (hipStream_t)stream;
+  static const bool trace = std::getenv("SE3TN_TRACK_TRACE") != nullptr;   // developer switch: host-side timeline of the call
+  static double acc[6] = {0, 0, 0, 0, 0, 0};
+  static int ncall = 0;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = trace ? now() : 0.0;
   // start-up allocations (first call / larger frame): pinned staging for a whole frame, its device mirror, outputs
   const size_t need = 256 + (size_t)H * W * 5 + 64;
   if (need > c->trk_bytes) {
@@ -1093,11 +1105,16 @@ int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], cons
     HIPCHK(hipMalloc((void**)&c->trk_dev, need));
     c->trk_bytes = need;
   }
-  if (!c->trk_out_dev) {
-    HIPCHK(hipMalloc((void**)&c->trk_out_dev, 256));
-    HIPCHK(hipHostMalloc((void**)&c->trk_out_host, 256, hipHostMallocDefault));
+  if (!c->trk_out_host) {
+    // pose | trans | rot | completion word in MAPPED pinned host memory: the tail kernel writes them across the bus itself and the
+    // host polls the word -- no device-to-host copy, no stream wake-up on the per-frame critical path
+    HIPCHK(hipHostMalloc((void**)&c->trk_out_host, 256, hipHostMallocMapped));
+    std::memset(c->trk_out_host, 0, 256);
+    HIPCHK(hipHostGetDevicePointer((void**)&c->trk_out_dev, c->trk_out_host, 0));
     HIPCHK(hipMalloc((void**)&c->trk_rgbA, (size_t)RES * RES * 3));
     HIPCHK(hipMalloc((void**)&c->trk_depthA, (size_t)RES * RES * 2));
+    HIPCHK(hipStreamCreateWithFlags(&c->trk_copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->trk_copy_event, hipEventDisableTiming));
   }
   // predict.py:231-235: bbox of the previous pose (host float64, round half to even) -> crop window of image B;
   // :201-206: the same with the y axis flipped -> the renderer's window
@@ -1105,8 +1122,14 @@ int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], cons
   bbox_window(prev_pose, K, object_width_mm, 1000.0, winB, vu);
   bbox_window(prev_pose, K, object_width_mm, -1000.0, winA, nullptr);
   if (winB[2] <= winB[0] || winB[3] <= winB[1]) return fail(SE3TN_E_ARG, "se3tn_on_track: empty crop window (pose behind the camera?)");
+  // image A first: its four launches run on the device while the host stages the frame
+  uint8_t* rA = rgbA_dev ? rgbA_dev : c->trk_rgbA;
+  uint16_t* dA = depthA_dev ? depthA_dev : c->trk_depthA;
+  if (int rc = se3tn_render(c, m, prev_pose, K, winA, rA, dA, stream)) return rc;
+  const double t1 = trace ? now() : 0.0;
   // only the part of the frame the window covers travels: rows / columns [y0, y1) x [x0, x1) into pinned memory, ONE copy
-  // with the pose in front.  crop_bbox's canvas is zero outside the frame (Utils.py:327-342): outside this sub-image too.
+  // with the pose in front, on a copy stream of its own (beside the rasteriser, not behind it).  crop_bbox's canvas is zero
+  // outside the frame (Utils.py:327-342): outside this sub-image too.
   int x0 = winB[0] > 0 ? winB[0] : 0, x1 = winB[2] < W ? winB[2] : W;
   int y0 = winB[1] > 0 ? winB[1] : 0, y1 = winB[3] < H ? winB[3] : H;
   int sw = x1 - x0, sh = y1 - y0;
@@ -1126,10 +1149,10 @@ int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], cons
     }
   }
   const size_t bytes = d_off + (size_t)sw * sh * 2;
-  HIPCHK(hipMemcpyAsync(c->trk_dev, hp, bytes, hipMemcpyHostToDevice, st));
-  uint8_t* rA = rgbA_dev ? rgbA_dev : c->trk_rgbA;
-  uint16_t* dA = depthA_dev ? depthA_dev : c->trk_depthA;
-  if (int rc = se3tn_render(c, m, prev_pose, K, winA, rA, dA, stream)) return rc;
+  HIPCHK(hipMemcpyAsync(c->trk_dev, hp, bytes, hipMemcpyHostToDevice, c->trk_copy_stream));
+  HIPCHK(hipEventRecord(c->trk_copy_event, c->trk_copy_stream));
+  HIPCHK(hipStreamWaitEvent(st, c->trk_copy_event, 0));
+  const double t2 = trace ? now() : 0.0;
   // image A and image B in ONE preprocess launch (data_augmentation.py:124-189 for both, with poseA's z)
   CropArgs a;
   std::memcpy(a.mean, c->mean, sizeof(a.mean));
@@ -1147,12 +1170,37 @@ int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], cons
   a.overflow = c->overflow; a.offset_rule = c->offset_rule;
   c->in_split[0] = c->in_split[1] = a.split;
   HIPCHK(launch_preprocess(a, st));
+  const double t3 = trace ? now() : 0.0;
   float* trans_d = (float*)(c->trk_out_dev + 128);
   float* rot_d = (float*)(c->trk_out_dev + 144);
-  if (int rc = se3tn_infer(c, c->inA, c->inB, 1, SE3TN_NHWC, trans_d, rot_d, (const double*)c->trk_dev, (double*)c->trk_out_dev, stream))
-    return rc;
-  HIPCHK(hipMemcpyAsync(c->trk_out_host, c->trk_out_dev, 160, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  int* flag_d = (int*)(c->trk_out_dev + 192);
+  volatile int* flag_h = (volatile int*)(c->trk_out_host + 192);
+  const bool poll = !c->use_graphs && !c->prof;   // (a captured graph would replay a stale sequence number)
+  const int seq = ++c->tail_seq == 0 ? ++c->tail_seq : c->tail_seq;
+  c->tail_flag = poll ? flag_d : nullptr;
+  const int rc_inf = se3tn_infer(c, c->inA, c->inB, 1, SE3TN_NHWC, trans_d, rot_d, (const double*)c->trk_dev, (double*)c->trk_out_dev, stream);
+  c->tail_flag = nullptr;
+  if (rc_inf) return rc_inf;
+  const double t4 = trace ? now() : 0.0;
+  bool seen = false;
+  if (poll) {   // 5 ms of polling covers every healthy frame; anything slower (or a fault) falls through to the stream wait
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(5);
+    for (;;) {
+      for (int it = 0; it < 256 && !seen; ++it) seen = __atomic_load_n((const int*)flag_h, __ATOMIC_ACQUIRE) == seq;
+      if (seen || std::chrono::steady_clock::now() > t_end) break;
+    }
+  }
+  if (!seen) HIPCHK(hipStreamSynchronize(st));
+  if (trace) {
+    const double t5 = now();
+    const double d[6] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0};
+    for (int i = 0; i < 6; ++i) acc[i] += d[i];
+    if (++ncall % 200 == 0) {
+      std::fprintf(stderr, "se3tn_on_track host timeline (mean of 200, us): bbox+render enqueue %.1f | stage+H2D enqueue %.1f | preprocess enqueue %.1f | "
+                   "infer enqueue %.1f | wait for the tail's word %.1f | total %.1f\n", acc[0] / 200, acc[1] / 200, acc[2] / 200, acc[3] / 200, acc[4] / 200, acc[5] / 200);
+      for (double& v : acc) v = 0;
+    }
+  }
   std::memcpy(pose_out, c->trk_out_host, 128);
   if (trans_out) std::memcpy(trans_out, c->trk_out_host + 128, 12);
   if (rot_out) std::memcpy(rot_out, c->trk_out_host + 144, 12);

@@ -316,7 +316,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_gather_s2_kernel(const Con
   const int l31 = lane & 31, hh = lane >> 5;
 
   const int panels = a.groups * a.tiles_n;
+#if defined(SE3TN_GATHER_XCD_PIXELS)
+  // variant (EXPERIMENTS items 12, 42): an XCD owns a RANGE OF PIXEL TILES and walks every weight panel over it (its L2 keeps the
+  // input rows; the panels stream), instead of owning weight panels
+  const int tiles_m = (a.M + BM - 1) / BM, per_x = (tiles_m + 7) / 8;
+  const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int p = q % panels, mt = x * per_x + q / panels;
+  if (mt >= tiles_m) return;
+#else
   const int p = blockIdx.x % panels, mt = blockIdx.x / panels;
+#endif
   const int g = p / a.tiles_n, nt = p % a.tiles_n;
   const int m0 = mt * BM, n0 = nt * BN;
   const float* __restrict__ in = a.in + (size_t)g * a.in_gs;
@@ -722,7 +731,11 @@ static hipError_t launch_gather_nw(const ConvArgs& a, hipStream_t st) {
   hipError_t e = set_lds(kern, lds, attr);
   if (e != hipSuccess) return e;
   const int tiles_m = (a.M + BM - 1) / BM;
+#if defined(SE3TN_GATHER_XCD_PIXELS)
+  hipLaunchKernelGGL(kern, dim3(((tiles_m + 7) / 8) * 8 * a.tiles_n * a.groups), dim3(NW * 64), lds, st, a);
+#else
   hipLaunchKernelGGL(kern, dim3(tiles_m * a.tiles_n * a.groups), dim3(NW * 64), lds, st, a);
+#endif
   return hipGetLastError();
 }
 

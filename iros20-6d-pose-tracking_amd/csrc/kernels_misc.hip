@@ -164,7 +164,7 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ he
                                                     const float* __restrict__ fc_b,
                                                     float* __restrict__ logits, float* __restrict__ trans,
                                                     float* __restrict__ rot, const double* __restrict__ poseA,
-                                                    double* __restrict__ poseB, double tn, double rn) {
+                                                    double* __restrict__ poseB, double tn, double rn, int* done_flag, int done_seq) {
   __shared__ float part[4][3];
   __shared__ float outv[6];
   __shared__ float4 psum[3][256];
@@ -211,17 +211,24 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ he
     outv[k] = y;
     if (h == 0) { if (trans) trans[n * 3 + o] = y; }
     else        { if (rot) rot[n * 3 + o] = y; }
+    if (done_flag) __threadfence_system();   // (se3tn_on_track: the outputs live in mapped host memory)
   }
   if (poseA == nullptr) return;
   __syncthreads();
-  if (threadIdx.x == 0) pose_compose(outv, poseA + (size_t)n * 16, poseB + (size_t)n * 16, tn, rn);
+  if (threadIdx.x == 0) {
+    pose_compose(outv, poseA + (size_t)n * 16, poseB + (size_t)n * 16, tn, rn);
+    if (done_flag && n == 0) {   // the host polls this word instead of waiting for the stream (one frame, n == 1)
+      __threadfence_system();
+      __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,
-                       double rn, int n, hipStream_t st) {
+                       double rn, int n, hipStream_t st, int* done_flag, int done_seq) {
   hipLaunchKernelGGL(tail_kernel, dim3(n), dim3(1024), 0, st, head, fc_w, fc_b, logits, trans, rot,
-                     poseA, poseB, tn, rn);
+                     poseA, poseB, tn, rn, done_flag, done_seq);
   return hipGetLastError();
 }
 

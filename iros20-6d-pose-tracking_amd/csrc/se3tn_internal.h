@@ -260,7 +260,7 @@ hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* u
                              float* keep_out2, const TailArgs* tl, hipStream_t st, int mark_after_mid(void*), void* mark_ctx);
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,
-                       double rn, int n, hipStream_t st);
+                       double rn, int n, hipStream_t st, int* done_flag = nullptr, int done_seq = 0);
 // padded [n,h+2,w+2,c] NHWC interior -> [n,c,h,w]
 // split != 0: the source holds split rows (32 f16 hi | 32 f16 lo per 32-channel chunk)
 hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, int split,

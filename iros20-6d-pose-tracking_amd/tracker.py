@@ -97,6 +97,7 @@ class Tracker:
         self.prev_rgb = None
         self.prev_depth = None
         self.frame_cnt = 0
+        self._one_call_state = None
         self.one_call = True     # on_track through se3tn_on_track when the built-in rasteriser renders image A (False: step by step)
         self.errs = []
         dev = "cuda:%d" % device
@@ -205,30 +206,35 @@ class Tracker:
         """The whole frame in ONE library call (se3tn_on_track): compute_bbox, image A, both crops in one launch, network, pose
         update, read-back; the camera frame goes up as the window's rows / columns only, through pinned memory, together with the
         pose.  Same arithmetic as the step-by-step path below (tests/test_tracker_surface.py compares the two)."""
-        import ctypes as C
-        rgb = np.ascontiguousarray(current_rgb, dtype=np.uint8)
-        dep = _depth_u16(current_depth, rgb)
+        rgb = current_rgb if (type(current_rgb) is np.ndarray and current_rgb.dtype == np.uint8 and current_rgb.flags.c_contiguous) \
+            else np.ascontiguousarray(current_rgb, dtype=np.uint8)
         if rgb.ndim != 3 or rgb.shape[2] != 3:
             raise ValueError("rgb must be HxWx3 uint8")
-        P = np.ascontiguousarray(prev_pose, np.float64)
-        K = np.ascontiguousarray(self.K, np.float64)
-        pose = np.empty((4, 4), np.float64)
-        tr = np.empty(3, np.float32); ro = np.empty(3, np.float32)
-        bb = np.empty((4, 2), np.int32)
+        dep = current_depth if (type(current_depth) is np.ndarray and current_depth.dtype == np.uint16 and current_depth.flags.c_contiguous
+                                and current_depth.shape == rgb.shape[:2]) else _depth_u16(current_depth, rgb)
+        st = self._one_call_state
+        if st is None:   # per-tracker constants of the call: argument objects are built once, not per frame
+            import ctypes as C
+            from ._lib import check
+            from .engine import _stream_ptr
+            st = self._one_call_state = dict(
+                C=C, check=check, stream=_stream_ptr, fn=self.engine.lib.se3tn_on_track, P=np.empty((4, 4), np.float64),
+                K=np.ascontiguousarray(self.K, np.float64), pose=np.empty((4, 4), np.float64), tr=np.empty(3, np.float32),
+                ro=np.empty(3, np.float32), bb=np.empty((4, 2), np.int32))
+            for k, t in (("P", C.c_double), ("K", C.c_double), ("pose", C.c_double), ("tr", C.c_float), ("ro", C.c_float), ("bb", C.c_int32)):
+                st["p_" + k] = st[k].ctypes.data_as(C.POINTER(t))
+        C = st["C"]
+        st["P"][...] = prev_pose
         r = self.renderer
-        from ._lib import check
-        from .engine import _stream_ptr
-        check(self.engine.lib.se3tn_on_track(
-            self.engine._h, r._m, P.ctypes.data_as(C.POINTER(C.c_double)), K.ctypes.data_as(C.POINTER(C.c_double)),
-            C.c_double(float(self.object_width)), C.c_void_p(rgb.ctypes.data), C.c_void_p(dep.ctypes.data), int(rgb.shape[0]),
-            int(rgb.shape[1]), C.c_void_p(r.rgb.data_ptr()), C.c_void_p(r.depth.data_ptr()), pose.ctypes.data_as(C.POINTER(C.c_double)),
-            tr.ctypes.data_as(C.POINTER(C.c_float)), ro.ctypes.data_as(C.POINTER(C.c_float)), bb.ctypes.data_as(C.POINTER(C.c_int32)),
-            _stream_ptr()), "se3tn_on_track")
-        self.last_prediction = dict(trans=tr.reshape(1, 3), rot=ro.reshape(1, 3), bbox=bb)
+        st["check"](st["fn"](self.engine._h, r._m, st["p_P"], st["p_K"], C.c_double(float(self.object_width)), C.c_void_p(rgb.ctypes.data),
+                             C.c_void_p(dep.ctypes.data), int(rgb.shape[0]), int(rgb.shape[1]), C.c_void_p(r.rgb.data_ptr()),
+                             C.c_void_p(r.depth.data_ptr()), st["p_pose"], st["p_tr"], st["p_ro"], st["p_bb"], st["stream"]()),
+                    "se3tn_on_track")
+        self.last_prediction = dict(trans=st["tr"].reshape(1, 3).copy(), rot=st["ro"].reshape(1, 3).copy(), bbox=st["bb"].copy())
         self.prev_rgb = current_rgb
         self.prev_depth = current_depth
         self.frame_cnt += 1
-        return pose
+        return st["pose"].copy()
 
     def on_track_batch(self, prev_poses, rgbs, depths):
         """Extension: n independent (pose, frame) pairs of the SAME object in one engine call -- several

@@ -52,6 +52,16 @@ def test_self_launch_two_ranks_gloo_dry_run():
     assert 50e6 < chk["blob_bytes"] < 58e6, chk
 
 
+@pytest.mark.timeout(900)
+def test_self_launch_eight_ranks_gloo_dry_run():
+    """the rank count of the driver's scaling node (BASELINE configs[3]: 8 x 64 = 512 pairs): the launch path has counted to eight"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-run-gloo", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=dict(_env(), OMP_NUM_THREADS="1"), cwd=ROOT, timeout=840)
+    assert r.returncode == 0, r.stderr[-3000:]
+    chk = _check(_one_json_line(r.stdout), 8)
+    assert chk["gathered_rank_markers"] == [float(r + 1) for r in range(8)]
+
+
 @pytest.mark.timeout(600)
 def test_driver_launch_line_two_ranks_gloo_dry_run():
     """The round-end driver's command: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1

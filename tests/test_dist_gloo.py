@@ -58,9 +58,10 @@ def _worker(rank, world, port, q):
             ran.append(cid)
             e = np.sort(np.random.default_rng(cid).uniform(0.0, 0.08, 5 + cid))
             return {"add_errs": e * 2, "adi_errs": e, "add_auc": 0.0, "adi_auc": 0.0, "n": len(e)}
-        agg = S.eval_objects_parallel(range(1, 8), run_class, rank, world)
-        assert ran == [c for i, c in enumerate(range(1, 8)) if i % world == rank]
-        assert agg["n"] == sum(5 + c for c in range(1, 8)) and sorted(agg["per_class"]) == list(range(1, 8))
+        classes = range(1, 22) if world == 8 else range(1, 8)      # world 8: BASELINE configs[4] as named, 21 YCB-Video objects over 8 ranks
+        agg = S.eval_objects_parallel(classes, run_class, rank, world)
+        assert ran == [c for i, c in enumerate(classes) if i % world == rank]
+        assert agg["n"] == sum(5 + c for c in classes) and sorted(agg["per_class"]) == list(classes)
         assert 0 < agg["adi_auc"] <= 100 and agg["adi_auc"] > agg["add_auc"]
         # a class that fails on ONE rank: every rank still enters the gather and every rank raises (no hang)
         def run_class_bad(cid):
@@ -79,9 +80,11 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_plumbing():
-    world = 2
-    port = 29000 + os.getpid() % 2000
+@pytest.mark.parametrize("world", [2, 8], ids=["world2", "world8"])
+def test_gloo_plumbing(world):
+    """world 8 = the rank count of the node the round-end driver uses: 21 classes round-robin over 8 ranks (3 ranks x 3 + 5 x ... classes),
+    the blob broadcast to 7 receivers, 8-way pose gathers"""
+    port = 29000 + (os.getpid() + 97 * world) % 2000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -90,8 +93,8 @@ def test_two_rank_gloo_plumbing():
     res = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(60)
-    assert sorted(r[:2] for r in res) == [(0, "ok"), (1, "ok")], res
-    assert res[0][2] == res[1][2]          # every rank ends with the same aggregate
+    assert sorted(r[:2] for r in res) == [(r, "ok") for r in range(world)], res
+    assert len({r[2] for r in res}) == 1   # every rank ends with the same aggregate
 
 
 def test_shard_range_properties():
