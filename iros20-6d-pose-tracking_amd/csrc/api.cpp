@@ -72,6 +72,7 @@ struct se3tn_ctx {
   bool wino_fuse = true;                        // whole residual blocks as one fused launch sequence (SE3TN_WINOGRAD_FUSE=0: conv by conv)
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
   int* splitk_sem = nullptr;                    // [2 x SE3TN_SPLITK_MAX_TILES] arrival / seen counters of the fused split-K reduction (zero between launches)
+  bool small_kernels = true;                    // SE3TN_SMALL_KERNELS=0 (developer switch): batch 1-2 through the split-K kernels only
   bool splitk_fused = false;                    // SE3TN_SPLITK_FUSED=1 (developer switch): the reduction inside the split-K launch -- bitwise the same results,
                                                 // but SLOWER on this chip (363 vs 268 us per batch-1 forward: EXPERIMENTS item 41), so off
   size_t part_bytes = 0;
@@ -366,6 +367,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&c->splitk_sem, sizeof(int) * 2 * SE3TN_SPLITK_MAX_TILES);
     if (e == hipSuccess) e = hipMemset(c->splitk_sem, 0, sizeof(int) * 2 * SE3TN_SPLITK_MAX_TILES);
     if (const char* sf = std::getenv("SE3TN_SPLITK_FUSED")) c->splitk_fused = std::atoi(sf) != 0;
+    if (const char* sk = std::getenv("SE3TN_SMALL_KERNELS")) c->small_kernels = std::atoi(sk) != 0;
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(split-K workspace)"); }
     e = hipMalloc((void**)&c->zbuf, sizeof(unsigned long long) * RES * RES);
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(zbuf)"); }
@@ -801,6 +803,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
       a.wscale = WS + SL.conv_sc[id];
     } a.res = res; a.out = out; a.part = c->part; a.part_bytes = c->part_bytes;
     a.sem = c->splitk_fused ? c->splitk_sem : nullptr;
+    a.small_ok = c->small_kernels ? 1 : 0;
     a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
     a.H = hin; a.W = hin; a.Ho = (hin - 1) / stride + 1; a.Wo = a.Ho;
     a.M = n * a.Ho * a.Wo;

@@ -1,0 +1,159 @@
+// The 64 -> 64, 3x3, stride-1 convs of the trunk (ResnetBasicBlock convA2 / convB2 / convB3, network_modules.py:86-120) at batch
+// 1-2: the regime Tracker.on_track runs in (predict.py:416: one pair per frame, frames serial).
+//
+// At one pair a trunk conv is 1,936 pixels x 64 couts x K = 576: 0.14 GFLOP, 1.8 us of the matrix cores -- and the split-K path
+// (conv3x3_splitk_kernel + conv_reduce_kernel) took 15-17 us for it: two launches, a 6 MB partial-sum round trip, three latency-bound
+// K-steps per workgroup (EXPERIMENTS item 44).  This kernel needs neither a K split nor a reduction: 16-pixel tiles (4 x 4 outputs) x
+// all 64 couts give 121 tiles per image and branch = 242 workgroups for the A|B pair, one per CU, each holding the WHOLE weight tensor
+// of its branch (18 K-steps x 8 KB = 144 KB, the packed panels as they are) and its 6 x 6 x 64 input patch (9 KB) in LDS.
+//   * matrix instruction: v_mfma_f32_16x16x4_f32 (exact float32, like the 32x32x2 form elsewhere); A operand = weights, B operand =
+//     pixels, so a lane ends with ONE pixel x 4 consecutive couts (float4 bias / residual / store);  wave w = couts 16w..16w+15;
+//   * every byte is requested up front: 3 + 36 LDS-DMA instructions per thread (patch, then the 18 weight tiles in K order); K-step
+//     ks starts after `s_waitcnt vmcnt(2 (17 - ks))` + barrier -- the matrix work of the early steps runs under the arrival of the late ones;
+//   * a 16-byte LDS read feeds four MFMAs: the lane quarter q holds k = 4q..4q+3 of a 16-channel group, MFMA m takes element m of both
+//     operands (a permutation of k inside the group -- the same on both sides);
+//   * LDS images are XOR-swizzled like the other kernels' (weights: 16-byte column ^ ((row >> 1) & 7), applied on the DMA source
+//     address; patch: column ^ (patch pixel & 7)): a fragment read puts at most two lanes of a 16-lane group on one bank group;
+//   * two accumulators (the two 16-channel groups of a K-step) are added at the end: 144 dependent MFMAs would wait on each other;
+//   * stored padding: the input carries its zero border, the patch is read without bounds logic; only interiors are stored.
+// Float32 only; the f16x3 mode keeps the split-K kernels.  Results differ from the split-K path in the last bits (another summation
+// order), are bitwise reproducible, and do not depend on the batch (n = 1 and n = 2 use the same tiles).
+#include "mfma_common.h"
+
+namespace se3tn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int C64_PATCH_FLOATS = 36 * 64;            // 6 x 6 pixels x 64 channels
+constexpr int C64_TILE_FLOATS = 64 * 32;             // one K-step of weights: 64 couts x 32 channels
+constexpr int C64_KSTEPS = 18;                       // 2 channel chunks x 9 taps
+constexpr size_t C64_LDS_BYTES = (size_t)(C64_PATCH_FLOATS + C64_KSTEPS * C64_TILE_FLOATS) * sizeof(float);   // 156,672
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct C64Frag {
+  const float* smem;
+  int wrow_off[2];    // weight fragment: float offset inside a K-step tile for 16-channel group 0 / 1
+  int pix, q;         // lane's pixel (0..15) and quarter (0..3)
+};
+
+template <int KS>
+__device__ __forceinline__ void c64_kstep(const C64Frag& f, f32x4& acc0, f32x4& acc1) {
+  // everything issued before weight tile KS + 1 has arrived (the patch and tiles 0..KS): two DMA instructions per later tile
+  wait_vm<2 * (C64_KSTEPS - 1 - KS)>();
+  __syncthreads();
+  constexpr int ch = KS / 9, tap = KS % 9, r = tap / 3, s = tap % 3;
+  const int pp = ((f.pix >> 2) + r) * 6 + (f.pix & 3) + s;            // patch pixel of this lane's output pixel under tap (r, s)
+  const float* px = f.smem + pp * 64 + ch * 32;
+  const float* wt = f.smem + C64_PATCH_FLOATS + KS * C64_TILE_FLOATS;
+  const int sw = pp & 7;
+  const float4 x0 = *reinterpret_cast<const float4*>(px + ((f.q ^ sw) << 2));
+  const float4 x1 = *reinterpret_cast<const float4*>(px + (((4 + f.q) ^ sw) << 2));
+  const float4 w0 = *reinterpret_cast<const float4*>(wt + f.wrow_off[0]);
+  const float4 w1 = *reinterpret_cast<const float4*>(wt + f.wrow_off[1]);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, x0.x, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, x1.x, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, x0.y, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, x1.y, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, x0.z, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, x1.z, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, x0.w, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, x1.w, acc1, 0, 0, 0);
+}
+
+template <int KS>
+struct C64Run {
+  static __device__ __forceinline__ void go(const C64Frag& f, f32x4& a0, f32x4& a1) {
+    C64Run<KS - 1>::go(f, a0, a1);
+    c64_kstep<KS>(f, a0, a1);
+  }
+};
+template <>
+struct C64Run<-1> {
+  static __device__ __forceinline__ void go(const C64Frag&, f32x4&, f32x4&) {}
+};
+
+// grid: groups * n * 121 workgroups of 256 threads; EPI 0 = bias + ReLU, 1 = bias + residual + ReLU
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void conv64_small_kernel(const ConvArgs a, int n) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TPI = 121;                              // 11 x 11 tiles of 4 x 4 outputs per 44 x 44 image
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const int tile = b % TPI, img = (b / TPI) % n, g = b / (TPI * n);
+  const int ty = tile / 11, tx = tile - ty * 11;
+  const int Wp = a.W + 2;                               // 46
+  const float* __restrict__ in = a.in + (size_t)g * a.in_gs + ((size_t)(img * Wp + ty * 4) * Wp + tx * 4) * a.in_ld;   // patch origin (padded)
+  const float* __restrict__ wgt = a.w + (size_t)g * a.w_gs;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+  // ---- request everything: the patch (576 16-byte slots: pixel = slot >> 4, physical column = slot & 15) ...
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (j == 2 && wid != 0) break;                      // slots 512..575: the first wave only
+    const int slot = j * 256 + tid;
+    const int pp = slot >> 4, pc = slot & 15;
+    const int col = (pc & 8) | ((pc & 7) ^ (pp & 7));   // logical 16-byte column that belongs in this physical slot
+    const int py = pp / 6, pxx = pp - py * 6;
+    const unsigned voff = (unsigned)(((py * Wp + pxx) * a.in_ld + col * 4) * 4);
+    glds16<0>(in, voff, lds0 + (unsigned)((j * 256 + wid * 64) * 16));
+  }
+  // ... then the 18 weight tiles in K order (the packed panels [chunk][tap][64 couts][32]: 8 KB each, row r, column (tid & 7) ^ ((r >> 1) & 7))
+  {
+    const int r0 = tid >> 3;
+    const int c4 = (tid & 7) ^ ((r0 >> 1) & 7);
+    const unsigned wvoff = (unsigned)((r0 * 32 + c4 * 4) * 4);
+    const unsigned wl = lds0 + (unsigned)(C64_PATCH_FLOATS * 4 + wid * 1024);
+#pragma unroll
+    for (int ks = 0; ks < C64_KSTEPS; ++ks) {
+      glds16<0>(wgt + (size_t)ks * C64_TILE_FLOATS, wvoff, wl + (unsigned)(ks * C64_TILE_FLOATS * 4));
+      glds16<0>(wgt + (size_t)ks * C64_TILE_FLOATS + 1024, wvoff, wl + (unsigned)(ks * C64_TILE_FLOATS * 4 + 4096));
+    }
+  }
+
+  C64Frag f;
+  f.smem = smem;
+  f.pix = lane & 15;
+  f.q = lane >> 4;
+  {
+    const int row = wid * 16 + (lane & 15), sw = (row >> 1) & 7;
+    f.wrow_off[0] = row * 32 + ((f.q ^ sw) << 2);
+    f.wrow_off[1] = row * 32 + (((4 + f.q) ^ sw) << 2);
+  }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  C64Run<C64_KSTEPS - 1>::go(f, acc0, acc1);
+
+  // ---- epilogue: this lane = pixel (lane & 15), couts 16 wid + 4 (lane >> 4) .. + 3
+  const int c = wid * 16 + (lane >> 4) * 4;
+  const int ho = ty * 4 + (f.pix >> 2), wo = tx * 4 + (f.pix & 3);
+  const size_t opix = ((size_t)img * Wp + ho + 1) * Wp + wo + 1;
+  float4 v = make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
+  const float4 bias = *reinterpret_cast<const float4*>(a.bias + (size_t)g * a.bias_gs + c);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI == 1) r = *reinterpret_cast<const float4*>(a.res + (size_t)g * a.res_gs + opix * a.res_ld + c);
+  v = apply_epilogue<EPI>(v, bias, r);
+  *reinterpret_cast<float4*>(a.out + (size_t)g * a.out_gs + opix * a.out_ld + c) = v;
+}
+
+hipError_t launch_conv64_small(const ConvArgs& a, int n, int epi, hipStream_t st) {
+  static PerDeviceOnce attr0, attr1;
+  auto k0 = conv64_small_kernel<0>;
+  auto k1 = conv64_small_kernel<1>;
+  bool* done = (epi == 1 ? attr1 : attr0).current();
+  if (!(done && *done)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(epi == 1 ? k1 : k0), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)C64_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    if (done) *done = true;
+  }
+  const int grid = a.groups * n * 121;
+  if (epi == 1) hipLaunchKernelGGL(k1, dim3(grid), dim3(256), C64_LDS_BYTES, st, a, n);
+  else hipLaunchKernelGGL(k0, dim3(grid), dim3(256), C64_LDS_BYTES, st, a, n);
+  return hipGetLastError();
+}
+
+}  // namespace se3tn

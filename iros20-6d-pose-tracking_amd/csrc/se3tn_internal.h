@@ -154,6 +154,7 @@ struct ConvArgs {
   // nullptr = separate conv_reduce_kernel launch.  epi / outf / resf: the epilogue the in-kernel reduction applies
   int* sem;
   int epi, outf, resf, rpt;   // rpt: reduce workgroups per output tile
+  int small_ok;               // the batch-1-2 kernels without a K split may be used (SE3TN_SMALL_KERNELS=0 switches them off)
   // f16x3 mode: per-cout power-of-two weight scale (acc * wscale = true sum), overflow flag,
   // fast = 0 (f32 everywhere) | 1 | 2 (see launch_conv3x3)
   const float* wscale;
@@ -258,6 +259,8 @@ hipError_t launch_wino64(const float* in, int in_ld, int in_gs, const float* U, 
 // mark_after_mid: optional profiling hook called between conv1 and conv2 (returns non-zero on error)
 hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* uscale2, const float* bias2, float* out2, int keep_mid,
                              float* keep_out2, const TailArgs* tl, hipStream_t st, int mark_after_mid(void*), void* mark_ctx);
+// the 64 -> 64 trunk convs at batch 1-2 without a K split (conv64_small.hip)
+hipError_t launch_conv64_small(const ConvArgs& a, int n, int epi, hipStream_t st);
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,
                        double rn, int n, hipStream_t st, int* done_flag = nullptr, int done_seq = 0);
