@@ -59,6 +59,8 @@ _SIGS = {
     "se3tn_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "se3tn_set_offset_rule": (C.c_int, [C.c_void_p, C.c_int]),
     "se3tn_get_offset_rule": (C.c_int, [C.c_void_p]),
+    "se3tn_set_small_kernels": (C.c_int, [C.c_void_p, C.c_int]),
+    "se3tn_get_small_kernels": (C.c_int, [C.c_void_p]),
     "se3tn_set_raster_rule": (C.c_int, [C.c_void_p, C.c_int]),
     "se3tn_get_raster_rule": (C.c_int, [C.c_void_p]),
     "se3tn_set_winograd": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

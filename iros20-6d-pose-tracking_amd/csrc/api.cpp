@@ -751,17 +751,25 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
     return fail(SE3TN_E_STATE, "se3tn_infer: f16x3 split panels not derived (se3tn_set_precision after the weights are bound)");
   const float* WS = c->split_w;
   const SplitLayout& SL = c->SL;
-  if (want_split)
-    HIPCHK(launch_stem(A, B, WS + SL.stem_ws, W + L.stem_b, WS + SL.stem_sc, c->stem, n, st));
-  else
-    HIPCHK(launch_stem(A, B, W + L.stem_w, W + L.stem_b, nullptr, c->stem, n, st));
-  HIPCHK((hipError_t)prof_mark(c, st, "stem7x7_mfma", false));
   const bool fast = c->prec == SE3TN_PREC_F16X3;  // both the big-tile and the split-K kernels
   c->last_fast = fast;
+  // batch 1-2 (the per-frame regime): stem + max-pool of both branches in ONE launch of 16-pool-pixel tiles; the 88 x 88 x 128 stem
+  // map is not stored, so a caller who asked for the intermediates gets the batch-64 pair
+  const bool small_stem = c->small_kernels && !want_split && !c->keep_intermediates && n <= SE3TN_STEM_SMALL_MAX_N;
+  if (small_stem) {
+    HIPCHK(launch_stem_pool_small(A, B, W + L.stem_w, W + L.stem_b, c->pool, n, st));
+    HIPCHK((hipError_t)prof_mark(c, st, "stem7x7 + maxpool [small tiles]", false));
+  } else {
+    if (want_split)
+      HIPCHK(launch_stem(A, B, WS + SL.stem_ws, W + L.stem_b, WS + SL.stem_sc, c->stem, n, st));
+    else
+      HIPCHK(launch_stem(A, B, W + L.stem_w, W + L.stem_b, nullptr, c->stem, n, st));
+    HIPCHK((hipError_t)prof_mark(c, st, "stem7x7_mfma", false));
 #if !defined(SE3TN_ABLATE_POOL)   // (timing-only variant build: what the step costs WITHOUT the pool pass -- EXPERIMENTS item 43)
-  HIPCHK(launch_maxpool(c->stem, c->pool, n, fast ? 1 : 0, st));
+    HIPCHK(launch_maxpool(c->stem, c->pool, n, fast ? 1 : 0, st));
 #endif
-  HIPCHK((hipError_t)prof_mark(c, st, "maxpool3x3s2", false));
+    HIPCHK((hipError_t)prof_mark(c, st, "maxpool3x3s2", false));
+  }
 
   auto conv = [&](ConvId id, const float* in, int in_ld, int in_gs, const float* res, int res_ld, int res_gs,
                   float* out, int out_ld, int out_gs, int hin, int stride, int epi, const char* name) -> int {
@@ -1017,6 +1025,13 @@ int se3tn_set_raster_rule(se3tn_ctx* c, int sub_bits) {
   return SE3TN_OK;
 }
 int se3tn_get_raster_rule(const se3tn_ctx* c) { return c ? c->raster_sub_bits : -1; }
+
+int se3tn_set_small_kernels(se3tn_ctx* c, int on) {
+  if (!c) return fail(SE3TN_E_ARG, "null ctx");
+  c->small_kernels = on != 0;
+  return SE3TN_OK;
+}
+int se3tn_get_small_kernels(const se3tn_ctx* c) { return c ? (c->small_kernels ? 1 : 0) : -1; }
 
 int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const double K[9], const int32_t window[4],
                  uint8_t* rgb, uint16_t* depth, void* stream) {

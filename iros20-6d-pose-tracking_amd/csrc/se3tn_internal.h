@@ -259,6 +259,11 @@ hipError_t launch_wino64(const float* in, int in_ld, int in_gs, const float* U, 
 // mark_after_mid: optional profiling hook called between conv1 and conv2 (returns non-zero on error)
 hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* uscale2, const float* bias2, float* out2, int keep_mid,
                              float* keep_out2, const TailArgs* tl, hipStream_t st, int mark_after_mid(void*), void* mark_ctx);
+// stem + max-pool of both branches in one launch at batch 1-2 (stem_pool_small.hip)
+#ifndef SE3TN_STEM_SMALL_MAX_N
+#define SE3TN_STEM_SMALL_MAX_N 2
+#endif
+hipError_t launch_stem_pool_small(const float* inA, const float* inB, const float* w, const float* bias, float* pool, int n, hipStream_t st);
 // the 64 -> 64 trunk convs at batch 1-2 without a K split (conv64_small.hip)
 hipError_t launch_conv64_small(const ConvArgs& a, int n, int epi, hipStream_t st);
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,

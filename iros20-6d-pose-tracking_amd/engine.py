@@ -142,6 +142,14 @@ class Engine:
     def get_offset_rule(self):
         return "numpy2" if self.lib.se3tn_get_offset_rule(self._h) == _lib.OFFSET_RULE_NUMPY2 else "numpy1"
 
+    def set_small_kernels(self, on=True):
+        """Batches of 1-2 pairs through the small-tile stem + pool / trunk kernels (default) or through the general kernels (False):
+        include/se3tracknet.h, se3tn_set_small_kernels."""
+        check(self.lib.se3tn_set_small_kernels(self._h, 1 if on else 0), "se3tn_set_small_kernels")
+
+    def get_small_kernels(self):
+        return bool(self.lib.se3tn_get_small_kernels(self._h))
+
     def set_raster_rule(self, sub_bits):
         """Sub-pixel bits of the rasteriser's window coordinates: 4 (default: the software GL the goldens were rendered on, = the GL
         minimum) or 8 (what desktop GPUs report for GL_SUBPIXEL_BITS).  include/se3tracknet.h: se3tn_set_raster_rule."""

@@ -223,13 +223,16 @@ def test_fused_trunk_winograd_vs_direct_and_oracle(se3, golden_dir):
     _close("rot_logit", lg_w[:, 3:], ref["rot_logit"], 0, NET_TOL)
     _close("trans vs golden", ow["trans"].cpu(), torch.from_numpy(g["trans"]), 0, NET_TOL)
     _close("rot vs golden", ow["rot"].cpu(), torch.from_numpy(g["rot"]), 0, NET_TOL)
-    # every pair of a forced batch of 5 equals that pair alone through the same kernel (a workgroup never spans two images): bitwise
+    # every pair of a forced batch of 5 equals that pair alone through the same kernel (a workgroup never spans two images): bitwise.
+    # (The batch-1-2 stem / trunk kernels are another algorithm -- switched off here so that one pair runs the same kernels as five.)
+    eng.set_small_kernels(False)
     A5, B5 = Fx.net_inputs(9, 5)
     m(A5.cuda(), B5.cuda(), return_feature=False)
     q5 = eng.debug_buffer("q64", 5).clone()
     l5 = eng.logits(5).cpu().clone()
     m(A5[3:4].cuda(), B5[3:4].cuda(), return_feature=False)
     assert torch.equal(eng.debug_buffer("q64", 1)[0], q5[3]), "fused trunk: a pair's result depends on its batch"
+    eng.set_small_kernels(True)
     ref5 = O.forward(sd, A5, B5)
     _close("n5 logits", l5, torch.cat([ref5["trans_logit"], ref5["rot_logit"]], 1), 0, NET_TOL)
     # the default rule (rounds of the 256 CUs at least 55 % full): n = 64 -> 2 | 1 rounds, n = 48 -> 1.5 | 0.75: all four launches;
