@@ -842,18 +842,11 @@ static int pick_slices(const ConvArgs& a, int cin, int cout, int big_tile_rows, 
 #ifndef SE3TN_CONV64_SMALL_MAX_N
 #define SE3TN_CONV64_SMALL_MAX_N 2   // the trunk convs of up to this many pairs take conv64_small_kernel (0: never)
 #endif
-#ifndef SE3TN_CONV_STREAM_MAX_N
-#define SE3TN_CONV_STREAM_MAX_N 2    // convAB1 / convAB2 / trans|rot conv1 of up to this many pairs take conv_small_stream_kernel (0: never)
-#endif
 hipError_t launch_conv3x3(const ConvArgs& a0, int cin, int cout, int stride, int epi, hipStream_t st) {
   ConvArgs a = a0;
   if (!a.fast && cin == 64 && cout == 64 && stride == 1 && a.W == 44 && a.H == 44 && epi != 2 && a.M % (44 * 44) == 0 &&
       a.M / (44 * 44) <= SE3TN_CONV64_SMALL_MAX_N && a.small_ok)
     return launch_conv64_small(a, a.M / (44 * 44), epi, st);
-  if (!a.fast && a.small_ok && SE3TN_CONV_STREAM_MAX_N > 0 && a.M % (a.Ho * a.Wo) == 0 && a.M / (a.Ho * a.Wo) <= SE3TN_CONV_STREAM_MAX_N) {
-    const hipError_t e = launch_conv_small_stream(a, a.M / (a.Ho * a.Wo), cin, cout, stride, epi, st);
-    if (e != hipErrorNotSupported) return e;
-  }
   a.slices = pick_slices(a, cin, cout, stride == 1 ? 256 : 128, cout >= 128 ? 128 : 64);
   if (a.slices > 0) {
     a.tiles_n = cout >= 128 ? cout / 128 : 1;

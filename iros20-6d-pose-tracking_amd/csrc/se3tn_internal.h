@@ -264,8 +264,6 @@ hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* u
 #define SE3TN_STEM_SMALL_MAX_N 2
 #endif
 hipError_t launch_stem_pool_small(const float* inA, const float* inB, const float* w, const float* bias, float* pool, int n, hipStream_t st);
-// convAB1 / convAB2 / trans|rot conv1 at batch 1-2 without a K split (conv_small_stream.hip); hipErrorNotSupported: not a shape of this family
-hipError_t launch_conv_small_stream(const ConvArgs& a, int n, int cin, int cout, int stride, int epi, hipStream_t st);
 // the 64 -> 64 trunk convs at batch 1-2 without a K split (conv64_small.hip)
 hipError_t launch_conv64_small(const ConvArgs& a, int n, int epi, hipStream_t st);
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
