@@ -104,6 +104,7 @@ struct se3tn_ctx {
   // se3tn_on_track: pinned host staging [pose 128 B | frame window rgb | depth], its device mirror, device outputs and their pinned copy
   uint8_t* trk_host = nullptr; uint8_t* trk_dev = nullptr; size_t trk_bytes = 0;
   uint8_t* trk_out_dev = nullptr; uint8_t* trk_out_host = nullptr;   // ONE mapped pinned block: device address | host address
+  int* tail_arrive = nullptr;                   // [max_batch] arrival counters of tail_kernel's 16 workgroups per pair (zero between launches)
   int* tail_flag = nullptr; int tail_seq = 0;   // set around se3tn_on_track's infer: the tail kernel stores tail_seq to this (mapped) word
   hipStream_t trk_copy_stream = nullptr; hipEvent_t trk_copy_event = nullptr;
   uint8_t* trk_rgbA = nullptr; uint16_t* trk_depthA = nullptr;
@@ -366,6 +367,8 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
     e = hipMalloc((void**)&c->part, c->part_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&c->splitk_sem, sizeof(int) * 2 * SE3TN_SPLITK_MAX_TILES);
     if (e == hipSuccess) e = hipMemset(c->splitk_sem, 0, sizeof(int) * 2 * SE3TN_SPLITK_MAX_TILES);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->tail_arrive, sizeof(int) * c->max_batch);
+    if (e == hipSuccess) e = hipMemset(c->tail_arrive, 0, sizeof(int) * c->max_batch);
     if (const char* sf = std::getenv("SE3TN_SPLITK_FUSED")) c->splitk_fused = std::atoi(sf) != 0;
     if (const char* sk = std::getenv("SE3TN_SMALL_KERNELS")) c->small_kernels = std::atoi(sk) != 0;
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(split-K workspace)"); }
@@ -386,7 +389,7 @@ void se3tn_destroy(se3tn_ctx* c) {
   if (!c) return;
   if (c->device >= 0) {
     float* bufs[] = {c->inA, c->inB, c->stem, c->pool, c->t64, c->q64, c->ab, c->ab_t, c->head,
-                     c->head_t, c->head_f, c->logits, c->fcpart, c->part, (float*)c->splitk_sem, c->blob_owned, c->split_w, c->wino_v, c->wino_m,
+                     c->head_t, c->head_f, c->logits, c->fcpart, c->part, (float*)c->splitk_sem, (float*)c->tail_arrive, c->blob_owned, c->split_w, c->wino_v, c->wino_m,
                      c->wino_u[0], c->wino_u[1], c->wino_u[2], c->wino_u[3], c->wino_u6[0], c->wino_u6[1], c->wino_u6[2], c->wino_u6[3],
                      c->wino_us[0], c->wino_us[1], c->wino_us[2], c->wino_us[3], c->wino_usc[0], c->wino_usc[1], c->wino_usc[2],
                      c->wino_usc[3], c->wino64_u[0], c->wino64_u[1], c->wino64_u[2], c->wino64_u[3]};
@@ -889,7 +892,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
     float* head_out = fast ? c->head_f : c->head;
     if ((rc = conv(LH2_2, c->head_t, 1024, 512, c->head, 1024, 512, head_out, 1024, 512, S4, 1, 1, "trans|rot conv2.conv2"))) return rc;
     c->head_final = head_out;
-    HIPCHK(launch_tail(head_out, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st, c->tail_flag, c->tail_seq));
+    HIPCHK(launch_tail(head_out, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st, c->fcpart, c->tail_arrive, c->tail_flag, c->tail_seq));
     HIPCHK((hipError_t)prof_mark(c, st, "tail avgpool+fc+tanh+pose", false));
   }
   if (c->prof) c->slot_launches[slot] = c->n_launch;

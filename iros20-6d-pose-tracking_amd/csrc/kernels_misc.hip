@@ -156,68 +156,86 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// 1024 threads: thread (grp, t) sums pixels [grp * 43, grp * 43 + 43) of channels 4t..4t+3 (43 loads, 11 in flight: the loop is a
-// latency chain -- one workgroup of 256 threads walking all 169 padded pixels took 11.8 us at batch 1), the four partial sums are
-// added in a fixed order
-__global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ head,
-                                                    const float* __restrict__ fc_w,
-                                                    const float* __restrict__ fc_b,
-                                                    float* __restrict__ logits, float* __restrict__ trans,
-                                                    float* __restrict__ rot, const double* __restrict__ poseA,
-                                                    double* __restrict__ poseB, double tn, double rn, int* done_flag, int done_seq) {
-  __shared__ float part[4][3];
-  __shared__ float outv[6];
-  __shared__ float4 psum[3][256];
-  const int n = blockIdx.x, t = threadIdx.x & 255, grp = threadIdx.x >> 8;
-  constexpr int PP = (S4 + 2) * (S4 + 2), PG = (PP + 3) / 4;
-  const float* src = head + (size_t)n * PP * 1024 + t * 4;
+// AdaptiveAvgPool2d(1) + Linear(512, 3) + tanh of both heads + the float64 pose update (se3_tracknet.py:100-110, datasets.py:159-175)
+// for the configurations whose last conv stores the head map (small batches; large ones fuse this into wino_tail_kernel).
+// 16 workgroups per pair, one per 64-channel slice: a single workgroup reading the whole 692 KB map is bound by what ONE compute
+// unit can pull (11.8 us at batch 1, however its loop is arranged: EXPERIMENTS item 47).  Thread (pg, col) sums pixels pg, pg + 16, ...
+// of channels 4 col .. 4 col + 3 (11 loads, all in flight); the 16 pixel groups, then the 16 columns' partial dot products, are added
+// in a fixed order; the slice's three partial logits go to fcpart[pair][head][slice][3] with device scope, and the LAST of the
+// 16 workgroups to arrive (a counter per pair, re-armed by that workgroup) adds the slices in slice order, applies bias + tanh and
+// composes the pose -- one launch, bitwise reproducible whatever the arrival order.
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ head, const float* __restrict__ fc_w,
+                                                   const float* __restrict__ fc_b, float* __restrict__ logits,
+                                                   float* __restrict__ trans, float* __restrict__ rot,
+                                                   const double* __restrict__ poseA, double* __restrict__ poseB, double tn, double rn,
+                                                   float* __restrict__ fcpart, int* __restrict__ arrive, int* done_flag, int done_seq) {
+  __shared__ float4 psum[16][16];
+  __shared__ float dots[16][3];
+  __shared__ int last;
+  const int i = blockIdx.x >> 4, sl16 = blockIdx.x & 15;    // pair, 64-channel slice (0-7 trans head, 8-15 rot head)
+  const int t = threadIdx.x, col = t & 15, pg = t >> 4;
+  constexpr int PP = (S4 + 2) * (S4 + 2);
+  const float* src = head + (size_t)i * PP * 1024 + sl16 * 64 + col * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  // History (profiles/EXPERIMENTS.md items 13): for this loop hipcc once kept the (x, y) sums swapped in their register pair and added
-  // with `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]`; on gfx950 that form returns wrong lanes 48-63 while another kernel's waves
-  // issue v_mfma_f32_32x32x16_f16 on the same CU (two f16x3 contexts in flight: wrong sums in 40-85 % of the launches).  The device
-  // code is therefore compiled without packed-float32 instructions (Makefile), and scripts/isa_lint.py checks the library for the form.
-  const int p_end = min(PP, (grp + 1) * PG);
-#pragma unroll 11
-  for (int p = grp * PG; p < p_end; ++p) {
-    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)p * 1024);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-  }
-  if (grp > 0) psum[grp - 1][t] = s;
-  __syncthreads();
-  if (grp == 0) {   // (whole waves: a group is four of the sixteen)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float4 v = psum[k][t];
+  for (int k = 0; k < (PP + 15) / 16; ++k) {
+    const int p = pg + 16 * k;
+    if (p < PP) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)p * 1024);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+  }
+  psum[pg][col] = s;
+  __syncthreads();
+  if (t < 16) {
+    float4 m = psum[0][t];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 v = psum[k][t]; m.x += v.x; m.y += v.y; m.z += v.z; m.w += v.w; }
     const float inv = (float)(S4 * S4);
-    s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv;
-    const int hd = t >> 7;            // 0 trans, 1 rot
-    const int cl = (t & 127) * 4;     // channel within the head
-    float acc[3];
+    m.x /= inv; m.y /= inv; m.z /= inv; m.w /= inv;
+    const int hd = sl16 >> 3, cl = (sl16 & 7) * 64 + t * 4;
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
       const float4 w = *reinterpret_cast<const float4*>(fc_w + (hd * 3 + o) * 512 + cl);
-      acc[o] = wave_sum(s.x * w.x + s.y * w.y + s.z * w.z + s.w * w.w);
+      dots[t][o] = m.x * w.x + m.y * w.y + m.z * w.z + m.w * w.w;
     }
-    if ((t & 63) == 0) { part[t >> 6][0] = acc[0]; part[t >> 6][1] = acc[1]; part[t >> 6][2] = acc[2]; }
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
-    const int k = threadIdx.x, h = k / 3, o = k - h * 3;
-    const float lg = part[2 * h][o] + part[2 * h + 1][o] + fc_b[h * 4 + o];
+  if (t == 0) {
+    float* mine = fcpart + ((size_t)i * 16 + sl16) * 3;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float d = dots[0][o];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) d += dots[k][o];
+      __hip_atomic_store(mine + o, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through: another XCD reads it below
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(arrive + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 15;
+    if (last) __hip_atomic_store(arrive + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last) return;                                   // (uniform: `last` is a shared word)
+  __shared__ float outv[6];
+  if (t < 6) {
+    const int h = t / 3, o = t - h * 3;
+    const float* p = fcpart + ((size_t)i * 16 + h * 8) * 3 + o;
+    float lg = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lg += __hip_atomic_load(p + k * 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lg += fc_b[h * 4 + o];
     const float y = tanhf(lg);
-    logits[n * 6 + k] = lg;
-    outv[k] = y;
-    if (h == 0) { if (trans) trans[n * 3 + o] = y; }
-    else        { if (rot) rot[n * 3 + o] = y; }
+    logits[i * 6 + t] = lg;
+    outv[t] = y;
+    if (h == 0) { if (trans) trans[i * 3 + o] = y; }
+    else        { if (rot) rot[i * 3 + o] = y; }
     if (done_flag) __threadfence_system();   // (se3tn_on_track: the outputs live in mapped host memory)
   }
   if (poseA == nullptr) return;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    pose_compose(outv, poseA + (size_t)n * 16, poseB + (size_t)n * 16, tn, rn);
-    if (done_flag && n == 0) {   // the host polls this word instead of waiting for the stream (one frame, n == 1)
+  if (t == 0) {
+    pose_compose(outv, poseA + (size_t)i * 16, poseB + (size_t)i * 16, tn, rn);
+    if (done_flag && i == 0) {   // the host polls this word instead of waiting for the stream (one frame, n == 1)
       __threadfence_system();
       __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -226,9 +244,9 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ he
 
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,
-                       double rn, int n, hipStream_t st, int* done_flag, int done_seq) {
-  hipLaunchKernelGGL(tail_kernel, dim3(n), dim3(1024), 0, st, head, fc_w, fc_b, logits, trans, rot,
-                     poseA, poseB, tn, rn, done_flag, done_seq);
+                       double rn, int n, hipStream_t st, float* fcpart, int* arrive, int* done_flag, int done_seq) {
+  hipLaunchKernelGGL(tail_kernel, dim3(n * 16), dim3(256), 0, st, head, fc_w, fc_b, logits, trans, rot,
+                     poseA, poseB, tn, rn, fcpart, arrive, done_flag, done_seq);
   return hipGetLastError();
 }
 

@@ -268,7 +268,7 @@ hipError_t launch_stem_pool_small(const float* inA, const float* inB, const floa
 hipError_t launch_conv64_small(const ConvArgs& a, int n, int epi, hipStream_t st);
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,
-                       double rn, int n, hipStream_t st, int* done_flag = nullptr, int done_seq = 0);
+                       double rn, int n, hipStream_t st, float* fcpart, int* arrive, int* done_flag = nullptr, int done_seq = 0);
 // padded [n,h+2,w+2,c] NHWC interior -> [n,c,h,w]
 // split != 0: the source holds split rows (32 f16 hi | 32 f16 lo per 32-channel chunk)
 hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, int split,
