@@ -70,13 +70,13 @@ def test_dropin_driver_writes_what_the_reference_driver_writes(golden, tmp_path)
                       trans_normalizer=0.03, rot_normalizer=30 * np.pi / 180)
     hip.engine.set_offset_rule("numpy2")
     seen = []
-    render = hip.renderer.render_device
+    on_track = hip.on_track
 
-    def recording(ob2cam, K, window, *a, **k):
-        out = render(ob2cam, K, window, *a, **k)
-        seen.append((out[0].cpu().numpy().copy(), out[1].cpu().numpy().view(np.uint16).copy()))
+    def recording(*a, **k):                     # image A of every frame: it stays in the renderer's device buffers on both code paths
+        out = on_track(*a, **k)
+        seen.append((hip.renderer.rgb.cpu().numpy().copy(), hip.renderer.depth.cpu().numpy().view(np.uint16).copy()))
         return out
-    hip.renderer.render_device = recording
+    hip.on_track = recording
     res2 = se3.sequence.predict_sequence_ycbineoat(hip, video, str(tmp_path / "res2" / VIDEO))
     d = float(np.abs(res2["poses"] - golden["poses"]).max())
     same = sum(int(np.array_equal(a, golden["rgbA"][i]) and np.array_equal(b, golden["depthA"][i])) for i, (a, b) in enumerate(seen))

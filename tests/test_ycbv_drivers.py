@@ -149,13 +149,13 @@ def test_dropin_ycbv_drivers_write_what_the_reference_drivers_write(golden, tree
     trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=OBJECT_WIDTH), mean, std, {"state_dict": sd}, model_path=ply)
     trk.engine.set_offset_rule("numpy2")                                         # like for like: the golden ran under NumPy 2
     seen = []
-    render = trk.renderer.render_device
+    on_track = trk.on_track
 
-    def recording(ob2cam, K, window, *a, **k):
-        out = render(ob2cam, K, window, *a, **k)
-        seen.append((out[0].cpu().numpy().copy(), out[1].cpu().numpy().view(np.uint16).copy()))
+    def recording(*a, **k):                     # image A of every frame: it stays in the renderer's device buffers on both code paths
+        out = on_track(*a, **k)
+        seen.append((trk.renderer.rgb.cpu().numpy().copy(), trk.renderer.depth.cpu().numpy().view(np.uint16).copy()))
         return out
-    trk.renderer.render_device = recording
+    trk.on_track = recording
     # ---- predictSequenceYcb with --reinit_frames ------------------------------------------------------------------------------
     out = str(tmp_path / "out")
     res = se3.sequence.predict_sequence_ycb(trk, os.path.join(tree, "data_organized", "0048"), YF.CLASS_ID, out,
