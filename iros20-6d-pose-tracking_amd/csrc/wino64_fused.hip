@@ -25,9 +25,6 @@
 // fragment layout as conv3x3_mfma.hip / wino_mfma.hip.
 #include "mfma_common.h"
 
-#ifndef W64_RES_HOIST
-#define W64_RES_HOIST 0    // 1: the <1> instances request their 16 residual float4s before the store loop (prepared variant, see the epilogue)
-#endif
 #ifndef W64_KNOCKOUT
 #define W64_KNOCKOUT 0   // timing knock-outs (wrong results): bit 0 = no window reads from the LDS patch;
                          // wino64_regv_kernel: bit 1 = no U loads after the first, bit 2 = no window reads
@@ -335,33 +332,11 @@ __global__ __launch_bounds__(512) void wino64_fused_kernel(const Wino64Args a) {
   const float* __restrict__ res = (EPI == 1) ? a.res + (size_t)g * a.res_gs : nullptr;
   float* __restrict__ out = a.out + (size_t)g * a.out_gs;
   const int c4 = (tid & 15) * 4;
-#if W64_RES_HOIST
-  // PREPARED, NOT MEASURED (compiled only with -DW64_RES_HOIST=1; profiles/EXPERIMENTS.md item 39 (d)): the store loop below reads one
-  // residual float4 per iteration and waits for it before its store -- 16 dependent memory latencies per thread in the <1> instances,
-  // which run 4-6 us longer per launch than the <0> ones.  Here all 16 are requested before the barrier (the accumulators are dead:
-  // 64 registers free), so they arrive while the last waves still stage Y.  Same additions in the same order: bit-identical output.
-  float4 rr[16];
-  if constexpr (EPI == 1) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int p = (k * 512 + tid) >> 4;
-      int t = p >> 2;
-      const int o = p & 3;
-      t = t < W64_TILES * W64_TILES ? t : W64_TILES * W64_TILES - 1;   // the 28 idle slots read a valid address, value unused
-      const int ty = t / W64_TILES, tx = t - ty * W64_TILES;
-      const int oy = y0 + 2 * ty + (o >> 1) + 1, ox = x0 + 2 * tx + (o & 1) + 1;
-      rr[k] = *reinterpret_cast<const float4*>(res + ((size_t)(img * HP + oy) * HP + ox) * a.res_ld + c4);
-    }
-  }
-#endif
+  // (The residual reads of the <1> instances requested before this barrier instead of inside the store loop -- -DW64_RES_HOIST=1 of
+  // round 4 -- were measured in round 5: 38,162 / 37,983 against 38,153 / 38,098 pairs/s, no gain; the variant is gone.)
   __syncthreads();
   const float4 b = *reinterpret_cast<const float4*>(bias + c4);
-#if W64_RES_HOIST
-  if constexpr (EPI == 1) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) once, before the first store (item 38)
-#pragma unroll
-#else
 #pragma unroll 4
-#endif
   for (int k = 0; k < 16; ++k) {
     const int p = (k * 512 + tid) >> 4;          // (tile, pixel) index: 484 of the 512 are real
     const int t = p >> 2, o = p & 3;
@@ -372,11 +347,7 @@ __global__ __launch_bounds__(512) void wino64_fused_kernel(const Wino64Args a) {
       float4 v = *reinterpret_cast<const float4*>(smem + t * YS + o * 64 + c4);
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
       if (EPI == 1) {
-#if W64_RES_HOIST
-        const float4 r = rr[k];
-#else
         const float4 r = *reinterpret_cast<const float4*>(res + pix * a.res_ld + c4);
-#endif
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       }
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
