@@ -121,6 +121,36 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 176 * 176; ++i) sum_c += hc[i];
   printf("ok n=%d version=\"%s\" bbox0=(%d,%d) fill_sum=%llu fill_holes=%d crop_sum=%llu\n", n, se3tn_version(), vu[0], vu[1],
          sum_f, holes, sum_c);
+  /* one frame of Tracker.on_track in ONE call from C (round 5): an octahedron as the model, the 64 x 80 synthetic frame above as the
+   * camera image (HOST pointers), a small pin-hole camera.  Printed: the 4x4 estimate and checksums of image A. */
+  {
+    const float ov[18] = {0.05f, 0, 0, -0.05f, 0, 0, 0, 0.05f, 0, 0, -0.05f, 0, 0, 0, 0.05f, 0, 0, -0.05f};
+    const float on[18] = {1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1};
+    const float oc[18] = {1.0f, 0.2f, 0.2f, 0.2f, 1.0f, 0.2f, 0.2f, 0.2f, 1.0f, 0.9f, 0.9f, 0.1f, 0.1f, 0.9f, 0.9f, 0.9f, 0.1f, 0.9f};
+    const int32_t of[24] = {0, 2, 4, 2, 1, 4, 1, 3, 4, 3, 0, 4, 2, 0, 5, 1, 2, 5, 3, 1, 5, 0, 3, 5};
+    const double Kc[9] = {100.0, 0, 40.0, 0, 100.0, 32.0, 0, 0, 1};
+    const double mean[8] = {100, 110, 120, 900, 90, 95, 105, 850}, stdv[8] = {40, 45, 50, 300, 35, 42, 48, 280};
+    const double P0[16] = {0.8, -0.6, 0, 0.01, 0.6, 0.8, 0, -0.005, 0, 0, 1, 0.6, 0, 0, 0, 1};
+    double pose[16];
+    float tr[3], ro[3];
+    int32_t bb[8];
+    se3tn_mesh* mesh = NULL;
+    uint8_t* dIA; uint16_t* dDA;
+    if (hipMalloc((void**)&dIA, 176 * 176 * 3) || hipMalloc((void**)&dDA, 176 * 176 * 2)) return 3;
+    CHECK(se3tn_set_normalization(ctx, mean, stdv));
+    CHECK(se3tn_mesh_create(ctx, ov, on, oc, 6, of, 8, &mesh));
+    CHECK(se3tn_on_track(ctx, mesh, P0, Kc, 150.0, hrgb, hd, FH, FW, dIA, dDA, pose, tr, ro, bb, NULL));
+    uint8_t* hIA = (uint8_t*)malloc(176 * 176 * 3);
+    uint16_t* hDA = (uint16_t*)malloc(176 * 176 * 2);
+    hipMemcpy(hIA, dIA, 176 * 176 * 3, hipMemcpyDeviceToHost);
+    hipMemcpy(hDA, dDA, 176 * 176 * 2, hipMemcpyDeviceToHost);
+    unsigned long long sa = 0, sd = 0;
+    for (int i = 0; i < 176 * 176 * 3; ++i) sa += hIA[i] * (unsigned long long)(1 + i % 7);
+    for (int i = 0; i < 176 * 176; ++i) sd += hDA[i] * (unsigned long long)(1 + i % 5);
+    printf("track imageA_rgb=%llu imageA_depth=%llu bbox=%d,%d,%d,%d,%d,%d,%d,%d pose=", sa, sd, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5], bb[6], bb[7]);
+    for (int i = 0; i < 16; ++i) printf("%.17g%s", pose[i], i == 15 ? "\n" : ",");
+    se3tn_mesh_destroy(mesh);
+  }
   se3tn_destroy(ctx);
   return 0;
 }

@@ -61,7 +61,8 @@ def test_c_host_matches_oracle(tmp_path):
     rgb = np.stack([(xx + 2 * yy + 5 * c) & 255 for c in range(3)], -1).astype(np.uint8)
     bb = np.array([[-6, 10], [54, 10], [-6, 70], [54, 70]])          # (v, u) corners of the window (10, -6, 70, 54)
     _, crop_d = O.crop_bbox(rgb, filled, bb, (176, 176))
-    fields = dict(tok.split("=") for tok in out.stdout.split() if "=" in tok and not tok.startswith(("version", "bbox0")))
+    first = out.stdout.splitlines()[0]
+    fields = dict(tok.split("=") for tok in first.split() if "=" in tok and not tok.startswith(("version", "bbox0")))
     assert int(fields["fill_sum"]) == int(filled.astype(np.int64).sum()) and int(fields["fill_holes"]) == int((filled == 0).sum())
     assert int(fields["crop_sum"]) == int(crop_d.astype(np.int64).sum())
     raw = open(tmp_path / "out.bin", "rb").read()
@@ -73,3 +74,25 @@ def test_c_host_matches_oracle(tmp_path):
     for i in range(n):
         want = O.process_predict(poses[i], trans[i], rot[i])
         assert np.abs(poseB[i] - want).max() < 1e-12
+    # se3tn_on_track from C: the same frame through the oracle (its own render of image A, then the inner functions)
+    from oracle import ss_fast as SF
+    line = [l for l in out.stdout.splitlines() if l.startswith("track ")][0]
+    tf = dict(tok.split("=") for tok in line.split()[1:])
+    ov = np.array([[0.05, 0, 0], [-0.05, 0, 0], [0, 0.05, 0], [0, -0.05, 0], [0, 0, 0.05], [0, 0, -0.05]], np.float32)
+    on = (ov / 0.05).astype(np.float32)
+    oc = np.array([[1.0, .2, .2], [.2, 1.0, .2], [.2, .2, 1.0], [.9, .9, .1], [.1, .9, .9], [.9, .1, .9]], np.float32)
+    faces = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]])
+    Kc = np.array([[100.0, 0, 40.0], [0, 100.0, 32.0], [0, 0, 1]])
+    P0 = np.array([[0.8, -0.6, 0, 0.01], [0.6, 0.8, 0, -0.005], [0, 0, 1, 0.6], [0, 0, 0, 1]])
+    mean = np.array([100, 110, 120, 900, 90, 95, 105, 850.0]); std = np.array([40, 45, 50, 300, 35, 42, 48, 280.0])
+    bbA = O.compute_bbox(P0, Kc, 150.0, (1000, -1000, 1000))
+    win = (int(bbA[:, 1].min()), int(bbA[:, 0].min()), int(bbA[:, 1].max()), int(bbA[:, 0].max()))
+    rgbA, depthA = SF.render_vispy(ov, on, oc, faces, P0, Kc, win, numpy_rule="numpy1")
+    w7 = 1 + np.arange(rgbA.size) % 7
+    w5 = 1 + np.arange(depthA.size) % 5
+    assert int(tf["imageA_rgb"]) == int((rgbA.reshape(-1).astype(np.int64) * w7).sum())          # image A: every byte
+    assert int(tf["imageA_depth"]) == int((depthA.reshape(-1).astype(np.int64) * w5).sum())
+    want, aux = O.on_track(sd, P0, rgb, hd, rgbA, depthA, Kc, 150.0, mean, std)
+    assert [int(v) for v in tf["bbox"].split(",")] == aux["bbox"].reshape(-1).tolist()
+    got = np.array([float(v) for v in tf["pose"].split(",")]).reshape(4, 4)
+    assert np.abs(got - want).max() < 1e-5, np.abs(got - want).max()

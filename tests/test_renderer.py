@@ -277,3 +277,27 @@ def test_hip_rasteriser_vs_analytic_sphere(se3):
     _, depth2 = ren2.render_frame(P2, K)
     z2, nd2 = _analytic_sphere_frame(P2, K, W, H, radius)
     _check_against_sphere(depth2, z2, nd2, "HIP full-frame render")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subdiv,width,t", [(3, 100.0, (0.01, -0.02, 0.5)),     # the window cuts the sphere on all four sides
+                                            (0, 100.0, (0.02, 0.01, 0.35)),      # 20 big triangles, most of them crossing the window
+                                            (2, 150.0, (0.0, 0.0, 0.13)),        # the near plane (0.1 m) cuts the sphere
+                                            (4, 90.0, (0.06, 0.05, 0.6))])       # off-centre: two sides cut, thousands of small triangles
+def test_hip_rasteriser_clipping_equals_the_rules(se3, subdiv, width, t):
+    """Triangles that cross the frustum take raster_queue_kernel's clip path (Sutherland-Hodgman in clip space, polygon outline
+    walked edge by edge): byte equality with the statement of the GL implementation's rules, which oracle/ss_rules.py holds to the
+    live library on clipped triangles (tests/test_ss_rules.py::test_clipping)."""
+    from oracle import ss_fast as SF
+    m = Fx.icosphere(subdiv, 0.06, 7)
+    eng = se3.Engine(0, 1)
+    ren = se3.HipRenderer(eng, m)
+    P = Fx.pose(11, t)
+    win = se3.HipRenderer.gl_window(P, Fx.K_YCB, width)
+    rgb, depth = ren.render(P, Fx.K_YCB, win)
+    want_rgb, want_d = SF.render_vispy(*_mesh_args(m), P, Fx.K_YCB, win, numpy_rule="numpy1")
+    assert (want_d > 0).sum() > 3000
+    border = np.concatenate([want_d[0], want_d[-1], want_d[:, 0], want_d[:, -1]])
+    assert (border > 0).sum() > (0 if t[2] < 0.2 else 20)                       # the object really reaches the window's edge
+    assert np.array_equal(depth, want_d), ((depth != want_d).sum(), np.abs(depth.astype(int) - want_d.astype(int)).max())
+    assert np.array_equal(rgb, want_rgb), (rgb != want_rgb).any(2).sum()
