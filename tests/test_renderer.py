@@ -298,6 +298,9 @@ def test_hip_rasteriser_clipping_equals_the_rules(se3, subdiv, width, t):
     want_rgb, want_d = SF.render_vispy(*_mesh_args(m), P, Fx.K_YCB, win, numpy_rule="numpy1")
     assert (want_d > 0).sum() > 3000
     border = np.concatenate([want_d[0], want_d[-1], want_d[:, 0], want_d[:, -1]])
-    assert (border > 0).sum() > (0 if t[2] < 0.2 else 20)                       # the object really reaches the window's edge
+    if t[2] > 0.2:
+        assert (border > 0).sum() > 20                                           # the object really reaches the window's edge
+    else:
+        assert want_d[want_d > 0].min() <= 102                                   # ... or the near plane (100 mm)
     assert np.array_equal(depth, want_d), ((depth != want_d).sum(), np.abs(depth.astype(int) - want_d.astype(int)).max())
     assert np.array_equal(rgb, want_rgb), (rgb != want_rgb).any(2).sum()

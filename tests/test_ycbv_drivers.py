@@ -3,9 +3,11 @@ UNMODIFIED predict.predictSequenceYcb() (with --reinit_frames: PoseCNN re-initia
 eval_ycb.eval_one_class() and predict.use_posecnn_res() produce on the synthetic tree of oracle/ycbv_fixtures.py
 (oracle/make_ycbv_golden.py: reference Tracker on torch-CPU, its VispyRenderer on SwiftShader, under this image's NumPy 2).
 CPU: the PoseCNN lookup, the re-initialisation rule, the file layouts, the evaluator (a stub tracker replays the reference's poses).
-GPU: the drop-in drivers with the drop-in Tracker AND its own rasteriser write the same files in CLOSED LOOP: poses within 1e-5;
-image A byte-identical wherever the pose fed in is (initial / re-initialised frames, and every frame when the reference run's
-poses are fed: a pose that differs in its 7th digit can legitimately move a silhouette pixel or a millimetre boundary)."""
+GPU: the drop-in drivers with the drop-in Tracker AND its own rasteriser.  OPEN loop (every on_track call of the reference runs
+repeated with the pose the reference run fed): poses within 1e-5 (measured 5e-8), image A byte-identical, every frame.  CLOSED
+loop (the drivers as they are): same files, trajectories within 1e-3 -- a pose that differs in its 8th digit can move a vertex
+across a 1/16-pixel snapping boundary of the GL rules, a moved silhouette pixel is answered by the network with ~1e-4, and from
+there on the two runs are two runs (measured: 1e-7 until that happens, 1e-4 after)."""
 import os
 
 import numpy as np
@@ -151,8 +153,11 @@ def test_dropin_ycbv_drivers_write_what_the_reference_drivers_write(golden, tree
     seen = []
     on_track = trk.on_track
 
+    fed = []
+
     def recording(*a, **k):                     # image A of every frame: it stays in the renderer's device buffers on both code paths
         out = on_track(*a, **k)
+        fed.append(np.array(a[0]))
         seen.append((trk.renderer.rgb.cpu().numpy().copy(), trk.renderer.depth.cpu().numpy().view(np.uint16).copy()))
         return out
     trk.on_track = recording
@@ -165,13 +170,24 @@ def test_dropin_ycbv_drivers_write_what_the_reference_drivers_write(golden, tree
     same = sum(int(np.array_equal(a, golden["ycbv_rgbA"][i]) and np.array_equal(b, golden["ycbv_depthA"][i])) for i, (a, b) in enumerate(seen))
     print("predict_sequence_ycb vs predict.predictSequenceYcb (closed loop, 2 PoseCNN re-initialisations): %d / %d images A "
           "byte-identical, max |d pose| %.2e, ADD-S AUC %.6f vs %.6f" % (same, len(seen), d, res["adi_auc"], float(golden["ycbv_adi_auc"])))
-    assert len(seen) == 8 and d < 1e-5
-    _images_close(seen, golden["ycbv_rgbA"], golden["ycbv_depthA"], exact=(0, 3, 6))          # GT start + the two PoseCNN poses
-    for k in range(8):                                                                           # the reference run's own poses: every byte
-        rgbA, depthA = trk.render_window(golden["ycbv_poses_in"][k])
+    assert len(seen) == 8 and d < 1e-3                                                          # closed loop (see the module docstring)
+    near = [k for k in range(8) if np.abs(fed[k] - golden["ycbv_poses_in"][k]).max() < 1e-6]
+    assert {0, 3, 6} <= set(near)                                                               # GT start + the two PoseCNN poses: exact
+    _images_close([seen[k] for k in near], golden["ycbv_rgbA"][near], golden["ycbv_depthA"][near],
+                  exact=tuple(near.index(k) for k in (0, 3, 6)))
+    sdir = os.path.join(tree, "data_organized", "0048")
+    rf = sorted(os.listdir(os.path.join(sdir, "color"))); df = sorted(os.listdir(os.path.join(sdir, "depth_filled")))
+    d0 = 0.0
+    for k in range(8):                                                                           # OPEN loop: the reference run's own inputs
+        got = on_track(golden["ycbv_poses_in"][k], se3.sequence.read_rgb(os.path.join(sdir, "color", rf[k + 1])),
+                       se3.sequence.read_depth_mm(os.path.join(sdir, "depth_filled", df[k + 1])))
+        d0 = max(d0, float(np.abs(got - golden["ycbv_poses"][k + 1]).max()))
+        rgbA = trk.renderer.rgb.cpu().numpy(); depthA = trk.renderer.depth.cpu().numpy().view(np.uint16)
         assert np.array_equal(rgbA, golden["ycbv_rgbA"][k]) and np.array_equal(depthA, golden["ycbv_depthA"][k]), k
+    print("open loop (the 8 on_track calls of the reference's predictSequenceYcb run): max |d pose| %.2e, 8 / 8 images A byte-identical" % d0)
+    assert d0 < 1e-5
     seen.clear()
-    assert abs(res["adi_auc"] - float(golden["ycbv_adi_auc"])) < 1e-3           # (printed with 4 decimals by the reference; errors move by 1e-6)
+    assert abs(res["adi_auc"] - float(golden["ycbv_adi_auc"])) < 5e-3           # (printed with 4 decimals by the reference; errors move by 1e-6)
     # ---- getResultsYcb + eval_one_class ---------------------------------------------------------------------------------------------
     seen.clear()
     rdir = str(tmp_path / "res")
@@ -183,10 +199,32 @@ def test_dropin_ycbv_drivers_write_what_the_reference_drivers_write(golden, tree
     print("get_results_ycb vs predict.getResultsYcb: %d / %d images A byte-identical, max |d pose| %.2e; eval_one_class ADD-S / ADD AUC "
           "%.6f / %.6f vs the reference evaluator on the reference's files %.6f / %.6f" % (
               same2, len(seen), d2, ev["adi_auc"], ev["add_auc"], float(golden["eval_adi_auc"]), float(golden["eval_add_auc"])))
-    assert len(seen) == 13 and d2 < 1e-5
-    _images_close(seen, golden["res_rgbA"], golden["res_depthA"], exact=(0, 8))                # the two GT-initialised first frames
-    for k in range(13):
-        rgbA, depthA = trk.render_window(golden["res_poses_in"][k])
+    # CLOSED loop: the GL rules snap vertices to 1/16 pixel, so a pose that differs in its 8th digit can move a silhouette pixel, and
+    # the network answers a moved silhouette pixel with ~1e-4 (measured: frames 0-4 of 0048 within 1e-7, then 14 pixels of image A
+    # move and frames 5-7 sit 7e-5 .. 1e-4 from the reference run; 0050 within 1e-7 throughout; scripts/ycbv_loop_diag.py).  The
+    # same happens between two machines running the reference.  So: closed loop within 1e-3 and images compared while the pose fed
+    # is still the reference run's to 1e-6; the 1e-5 bar is held OPEN loop below, frame by frame, on the reference run's own inputs.
+    assert len(seen) == 13 and d2 < 1e-3
+    fed2 = fed[-13:]
+    near = [k for k in range(13) if np.abs(fed2[k] - golden["res_poses_in"][k]).max() < 1e-6]
+    assert 0 in near and 8 in near and len(near) >= 6                                          # (both GT-initialised first frames)
+    _images_close([seen[k] for k in near], golden["res_rgbA"][near], golden["res_depthA"][near],
+                  exact=(near.index(0), near.index(8)))
+    want = np.concatenate([golden["res_poses"][1:9], golden["res_poses"][10:]])
+    frames = []
+    for s_id, n in ((48, 9), (50, 6)):
+        sdir = os.path.join(tree, "data_organized", "%04d" % s_id)
+        rf = sorted(os.listdir(os.path.join(sdir, "color"))); df = sorted(os.listdir(os.path.join(sdir, "depth_filled")))
+        frames += [(se3.sequence.read_rgb(os.path.join(sdir, "color", rf[i])),
+                    se3.sequence.read_depth_mm(os.path.join(sdir, "depth_filled", df[i]))) for i in range(1, n)]
+    d3 = 0.0
+    for k in range(13):                                                                          # OPEN loop: the reference run's inputs
+        got = on_track(golden["res_poses_in"][k], *frames[k])
+        d3 = max(d3, float(np.abs(got - want[k]).max()))
+        rgbA = trk.renderer.rgb.cpu().numpy(); depthA = trk.renderer.depth.cpu().numpy().view(np.uint16)
         assert np.array_equal(rgbA, golden["res_rgbA"][k]) and np.array_equal(depthA, golden["res_depthA"][k]), k
-    assert np.abs(ev["adi_errs"] - golden["eval_adi_errs"]).max() < 2e-5 and np.abs(ev["add_errs"] - golden["eval_add_errs"]).max() < 2e-5
+    print("open loop (every on_track call of the reference's getResultsYcb run, its own pose fed): max |d pose| %.2e, 13 / 13 images A "
+          "byte-identical" % d3)
+    assert d3 < 1e-5
+    assert np.abs(ev["adi_errs"] - golden["eval_adi_errs"]).max() < 2e-4 and np.abs(ev["add_errs"] - golden["eval_add_errs"]).max() < 2e-4
     assert abs(ev["adi_auc"] - float(golden["eval_adi_auc"])) < 5e-3 and abs(ev["add_auc"] - float(golden["eval_add_auc"])) < 5e-3
