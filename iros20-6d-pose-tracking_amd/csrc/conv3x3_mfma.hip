@@ -842,11 +842,29 @@ static int pick_slices(const ConvArgs& a, int cin, int cout, int big_tile_rows, 
 #ifndef SE3TN_CONV64_SMALL_MAX_N
 #define SE3TN_CONV64_SMALL_MAX_N 2   // the trunk convs of up to this many pairs take conv64_small_kernel (0: never)
 #endif
+#ifndef SE3TN_SLICES_SMALL_MAX_N
+#define SE3TN_SLICES_SMALL_MAX_N 5   // up to this many pairs the 128 .. 512-channel convs take conv_slices_small_kernel (0: never)
+#endif
 hipError_t launch_conv3x3(const ConvArgs& a0, int cin, int cout, int stride, int epi, hipStream_t st) {
   ConvArgs a = a0;
   if (!a.fast && cin == 64 && cout == 64 && stride == 1 && a.W == 44 && a.H == 44 && epi != 2 && a.M % (44 * 44) == 0 &&
       a.M / (44 * 44) <= SE3TN_CONV64_SMALL_MAX_N && a.small_ok)
     return launch_conv64_small(a, a.M / (44 * 44), epi, st);
+  // batch 1-5, float32: the wide convs as one round of 128-pixel x 32-cout x channel-slice workgroups (conv_slices_small.hip)
+  if (!a.fast && a.small_ok && a.part && a.Ho * a.Wo > 0 && a.M % (a.Ho * a.Wo) == 0 && a.M / (a.Ho * a.Wo) <= SE3TN_SLICES_SMALL_MAX_N) {
+    const int sl = conv_slices_small_count(cin, stride, a.H);
+    if (sl > 0 && (size_t)sl * a.groups * a.M * cout * sizeof(float) <= a.part_bytes) {
+      a.slices = sl;
+      a.tiles_n = cout / 32;
+      a.sem = nullptr;
+      hipError_t e = launch_conv_slices_small(a, cin, stride, st);
+      if (e != hipSuccess) return e;
+      if (epi == 0) launch_reduce<0, MM_F32, FMT_F32, FMT_F32>(a, cout, st);
+      else if (epi == 1) launch_reduce<1, MM_F32, FMT_F32, FMT_F32>(a, cout, st);
+      else launch_reduce<2, MM_F32, FMT_F32, FMT_F32>(a, cout, st);
+      return hipGetLastError();
+    }
+  }
   a.slices = pick_slices(a, cin, cout, stride == 1 ? 256 : 128, cout >= 128 ? 128 : 64);
   if (a.slices > 0) {
     a.tiles_n = cout >= 128 ? cout / 128 : 1;

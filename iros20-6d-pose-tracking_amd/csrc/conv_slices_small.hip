@@ -1,0 +1,195 @@
+// The 128 .. 512-channel 3x3 convs (convAB1, convAB2, trans|rot conv1 / conv2: se3_tracknet.py:74-97, network_modules.py:86-120) at
+// batch 1-5: the regime Tracker.on_track runs in.  At one pair they are 136 of the forward's 230 us (EXPERIMENTS item 45), and what
+// bounds them is not bytes but the float32 matrix rate: 2.6 GFLOP / 157 TFLOP/s = 17 us on 256 compute units -- if every one of them
+// computes.  conv3x3_splitk_kernel's 128 x 128 tiles leave 8-32 output tiles per layer, so it cuts K into 12-48 runs of THREE K-steps:
+// each workgroup starts, waits for its first bytes, computes for a microsecond and stores a 64 KB partial tile (24 MB of partial sums
+// per trans|rot conv), and the grid is 1.5 waves of workgroups.
+//
+// Here a workgroup owns 128 output pixels of ONE image x 32 couts x ONE slice of the input channels with all nine taps:
+//   layer (cin, stride, out)       slices x channels   n-tiles   m-tiles/image   workgroups/pair   LDS
+//   convAB1      128, s2, 22x22        4 x 32              8          4               128          127 KB
+//   convAB2      256, s1, 22x22        8 x 32              8          4               256           66 KB
+//   trans|rot 1  256, s2, 11x11        8 x 32             32          1               256          111 KB
+//   trans|rot 2  512, s1, 11x11        8 x 64          2 x 16         1               256          123 KB
+// one round of workgroups per pair, 9 or 18 K-steps each, 4-8 partial sums per output instead of 12-48 (conv_reduce_kernel of
+// conv3x3_mfma.hip adds them in slice order and applies bias / residual / activation).  The slice count is a function of the layer
+// alone: a pair's bits do not depend on the batch it travels in.
+//   * taps share the input: the rows of the (zero-bordered) input under the tile are fetched ONCE as they lie -- a contiguous run of
+//     padded rows, 128 bytes (32 channels) per pixel -- and every tap reads them at its own offset; the weights are the packed
+//     panels as they are ([chunk][tap][cout][32]: a K-step's 32 x 32 tile is 4 KB contiguous);
+//   * every byte is requested up front with LDS-DMA (patch, then the nine weight tiles in tap order, per 32-channel chunk); K-step
+//     (chunk, tap) starts after `s_waitcnt vmcnt(what was issued after its tile)` + barrier;
+//   * v_mfma_f32_32x32x2_f32, A operand = weights, B operand = pixels: wave w = pixels 32 w .. 32 w + 31 of the tile x the 32 couts;
+//     a 16-byte LDS read feeds four MFMAs (lane half h holds channels 8 g + 4 h .. + 3 of an 8-channel group, MFMA e takes element e
+//     of both operands); two accumulators (even / odd groups) are added at the end;
+//   * LDS images XOR-swizzled like the other kernels' (16-byte column ^ ((row >> 1) & 7), applied on the DMA source address).
+// Float32 only (f16x3 keeps conv3x3_splitk_kernel).
+#include "mfma_common.h"
+
+namespace se3tn {
+
+template <int N>
+__device__ __forceinline__ void cs_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int CHUNKS, int PPMAX>
+struct CsGeom {
+  static constexpr int NB = (PPMAX * 8 + 255) / 256;          // patch DMA instructions per thread and chunk
+  static constexpr int PER_CHUNK = NB + 9;                    // + one per weight tile
+  static constexpr int TOTAL = CHUNKS * PER_CHUNK;
+  static constexpr int PATCH_FLOATS = NB * 256 * 4;
+  static constexpr int CHUNK_FLOATS = PATCH_FLOATS + 9 * 1024;
+  static constexpr size_t LDS = (size_t)CHUNKS * CHUNK_FLOATS * sizeof(float);
+};
+
+struct CsLane {
+  const float* smem;
+  int row, kh;      // lane & 31: cout row of the A fragment = pixel column of the B fragment; lane >> 5
+  int ppb, Wp;      // patch pixel under tap (0, 0) of this lane's output pixel; padded input width
+};
+
+template <class G, int KS>
+__device__ __forceinline__ void cs_kstep(const CsLane& f, f32x16& acc0, f32x16& acc1) {
+  constexpr int c = KS / 9, tap = KS % 9, r = tap / 3, s = tap % 3;
+  cs_wait_vm<G::TOTAL - (c * G::PER_CHUNK + G::NB + tap + 1)>();     // everything up to this K-step's weight tile has landed
+  __syncthreads();
+  const int pp = f.ppb + r * f.Wp + s;
+  const float* px = f.smem + c * G::CHUNK_FLOATS + pp * 32;
+  const float* wt = f.smem + c * G::CHUNK_FLOATS + G::PATCH_FLOATS + tap * 1024 + f.row * 32;
+  const int swp = (pp >> 1) & 7, sww = (f.row >> 1) & 7;
+  float4 x[4], w[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    x[g] = *reinterpret_cast<const float4*>(px + (((2 * g + f.kh) ^ swp) << 2));
+    w[g] = *reinterpret_cast<const float4*>(wt + (((2 * g + f.kh) ^ sww) << 2));
+  }
+#pragma unroll
+  for (int g = 0; g < 4; g += 2) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g].x, x[g].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g + 1].x, x[g + 1].x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g].y, x[g].y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g + 1].y, x[g + 1].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g].z, x[g].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g + 1].z, x[g + 1].z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g].w, x[g].w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g + 1].w, x[g + 1].w, acc1, 0, 0, 0);
+  }
+}
+
+template <class G, int KS>
+struct CsRun {
+  static __device__ __forceinline__ void go(const CsLane& f, f32x16& a0, f32x16& a1) {
+    CsRun<G, KS - 1>::go(f, a0, a1);
+    cs_kstep<G, KS>(f, a0, a1);
+  }
+};
+template <class G>
+struct CsRun<G, -1> {
+  static __device__ __forceinline__ void go(const CsLane&, f32x16&, f32x16&) {}
+};
+
+// grid: groups x images x m-tiles x n-tiles x slices workgroups of 256 threads (the slice is the fastest index: blockIdx % 8 is the XCD
+// a workgroup lands on, so the workgroups that read the same input channels share an L2).  ConvArgs: tiles_n = cout / 32, slices set.
+template <int CHUNKS, int STRIDE, int PPMAX>
+__global__ __launch_bounds__(256, 1) void conv_slices_small_kernel(const ConvArgs a, int tpi) {
+  using G = CsGeom<CHUNKS, PPMAX>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int sl = b % a.slices; b /= a.slices;
+  const int nt = b % a.tiles_n; b /= a.tiles_n;
+  const int HW = a.Ho * a.Wo, nimg = a.M / HW;
+  const int mt = b % (tpi * nimg), g = b / (tpi * nimg);
+  const int img = mt / tpi, t = mt - img * tpi;
+  const int Wp = a.W + 2;
+  const int m0 = t * 128, m1 = min(m0 + 127, HW - 1);
+  const int oy0 = m0 / a.Wo, oy1 = m1 / a.Wo;
+  const int PP = ((oy1 - oy0) * STRIDE + 3) * Wp;           // pixels of the patch: whole padded rows oy0 * STRIDE .. oy1 * STRIDE + 2
+  const size_t pix0 = ((size_t)img * (a.H + 2) + (size_t)oy0 * STRIDE) * Wp;
+  const float* __restrict__ in = a.in + (size_t)g * a.in_gs + pix0 * a.in_ld + (size_t)sl * CHUNKS * 32;
+  const int cout = a.tiles_n * 32;
+  // panels [chunk][tap][cout][32] of group g; this workgroup's rows nt * 32 .. + 31 of chunks sl * CHUNKS ..
+  const float* __restrict__ wgt = a.w + (size_t)g * a.w_gs + ((size_t)sl * CHUNKS * 9 * cout + (size_t)nt * 32) * 32;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    // the patch: slot = 16-byte column (slot & 7) of patch pixel (slot >> 3); slots past the patch re-read its last pixel
+#pragma unroll
+    for (int j = 0; j < G::NB; ++j) {
+      const int slot = j * 256 + tid;
+      const int p = min(slot >> 3, PP - 1);
+      const int col = (slot & 7) ^ ((p >> 1) & 7);
+      glds16<0>(in + c * 32, (unsigned)((p * a.in_ld + col * 4) * 4), lds0 + (unsigned)((c * G::CHUNK_FLOATS + (j * 256 + wid * 64) * 4) * 4));
+    }
+    // the nine 32 x 32 weight tiles: row tid >> 3, column (tid & 7) ^ ((row >> 1) & 7)
+    const int r0 = tid >> 3;
+    const unsigned wvoff = (unsigned)((r0 * 32 + (((tid & 7) ^ ((r0 >> 1) & 7)) << 2)) * 4);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+      glds16<0>(wgt + ((size_t)c * 9 + tap) * cout * 32, wvoff,
+                lds0 + (unsigned)((c * G::CHUNK_FLOATS + G::PATCH_FLOATS + tap * 1024 + wid * 256) * 4));
+  }
+
+  CsLane f;
+  f.smem = smem;
+  f.row = lane & 31;
+  f.kh = lane >> 5;
+  f.Wp = Wp;
+  const int m = min(m0 + wid * 32 + f.row, HW - 1);         // (rows past the image compute its last pixel again and are not stored)
+  const int oy = m / a.Wo, ox = m - oy * a.Wo;
+  f.ppb = (oy - oy0) * STRIDE * Wp + ox * STRIDE;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+  CsRun<G, CHUNKS * 9 - 1>::go(f, acc0, acc1);
+
+  // raw partial sums: part[slice][group][m][cout] (conv_reduce_kernel); this lane = pixel (lane & 31), couts 8 q + 4 kh .. + 3
+  if (m0 + wid * 32 + f.row < HW) {
+    float* __restrict__ part = a.part + (((size_t)sl * a.groups + g) * a.M + (size_t)img * HW + m) * cout + nt * 32 + f.kh * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(part + q * 8) = make_float4(acc0[4 * q + 0] + acc1[4 * q + 0], acc0[4 * q + 1] + acc1[4 * q + 1],
+                                                             acc0[4 * q + 2] + acc1[4 * q + 2], acc0[4 * q + 3] + acc1[4 * q + 3]);
+  }
+}
+
+template <int CHUNKS, int STRIDE, int PPMAX>
+static hipError_t launch_cs(const ConvArgs& a, int tpi, int grid, hipStream_t st) {
+  using G = CsGeom<CHUNKS, PPMAX>;
+  static_assert(G::LDS <= 160 * 1024 && G::TOTAL <= 63, "LDS image / DMA count out of range");
+  static PerDeviceOnce attr;
+  auto kern = conv_slices_small_kernel<CHUNKS, STRIDE, PPMAX>;
+  bool* done = attr.current();
+  if (!(done && *done)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    if (e != hipSuccess) return e;
+    if (done) *done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS, st, a, tpi);
+  return hipGetLastError();
+}
+
+// slices of the layer (0: this geometry has no kernel here)
+int conv_slices_small_count(int cin, int stride, int H) {
+  if (cin == 128 && stride == 2 && H == S2) return 4;
+  if (cin == 256 && stride == 1 && H == S3) return 8;
+  if (cin == 256 && stride == 2 && H == S3) return 8;
+  if (cin == 512 && stride == 1 && H == S4) return 8;
+  return 0;
+}
+
+// the conv part only: a.slices / a.tiles_n (= cout / 32) are set by the caller, who also launches the reduction
+hipError_t launch_conv_slices_small(const ConvArgs& a, int cin, int stride, hipStream_t st) {
+  const int HW = a.Ho * a.Wo, tpi = (HW + 127) / 128, nimg = a.M / HW;
+  const int grid = a.groups * nimg * tpi * a.tiles_n * a.slices;
+  if (cin == 128 && stride == 2) return launch_cs<1, 2, 690>(a, tpi, grid, st);
+  if (cin == 256 && stride == 1) return launch_cs<1, 1, 216>(a, tpi, grid, st);
+  if (cin == 256 && stride == 2) return launch_cs<1, 2, 552>(a, tpi, grid, st);
+  if (cin == 512 && stride == 1) return launch_cs<2, 1, 169>(a, tpi, grid, st);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace se3tn

@@ -266,6 +266,10 @@ hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* u
 hipError_t launch_stem_pool_small(const float* inA, const float* inB, const float* w, const float* bias, float* pool, int n, hipStream_t st);
 // the 64 -> 64 trunk convs at batch 1-2 without a K split (conv64_small.hip)
 hipError_t launch_conv64_small(const ConvArgs& a, int n, int epi, hipStream_t st);
+// the 128 .. 512-channel convs at batch 1-5: 128 pixels x 32 couts x one channel slice with all nine taps per workgroup
+// (conv_slices_small.hip); partial sums for conv_reduce_kernel
+int conv_slices_small_count(int cin, int stride, int H);
+hipError_t launch_conv_slices_small(const ConvArgs& a, int cin, int stride, hipStream_t st);
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,
                        double rn, int n, hipStream_t st, float* fcpart, int* arrive, int* done_flag = nullptr, int done_seq = 0);

@@ -10,7 +10,7 @@ for f in api.cpp weights.cpp; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result $FLAGS -x hip -c $f -o $OUT/$f.o &
 done
 NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"   # as in the Makefile
-for f in conv3x3_mfma.hip conv64_small.hip stem_pool_small.hip wino_mfma.hip wino64_fused.hip stem7x7_mfma.hip kernels_misc.hip raster.hip depth_fill.hip; do
+for f in conv3x3_mfma.hip conv64_small.hip conv_slices_small.hip stem_pool_small.hip wino_mfma.hip wino64_fused.hip stem7x7_mfma.hip kernels_misc.hip raster.hip depth_fill.hip; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result $NOPK $FLAGS -c $f -o $OUT/$f.o &
 done
 wait
