@@ -8,8 +8,9 @@
 // of its branch (18 K-steps x 8 KB = 144 KB, the packed panels as they are) and its 6 x 6 x 64 input patch (9 KB) in LDS.
 //   * matrix instruction: v_mfma_f32_16x16x4_f32 (exact float32, like the 32x32x2 form elsewhere); A operand = weights, B operand =
 //     pixels, so a lane ends with ONE pixel x 4 consecutive couts (float4 bias / residual / store);  wave w = couts 16w..16w+15;
-//   * every byte is requested up front: 3 + 36 LDS-DMA instructions per thread (patch, then the 18 weight tiles in K order); K-step
-//     ks starts after `s_waitcnt vmcnt(2 (17 - ks))` + barrier -- the matrix work of the early steps runs under the arrival of the late ones;
+//   * every byte is requested up front: 3 + 36 LDS-DMA instructions per thread (patch, then the 18 weight tiles in K order); the
+//     K-steps run in four groups, each starting with `s_waitcnt vmcnt(what was issued after its last tile)` + barrier -- the matrix
+//     work of the early groups runs under the arrival of the late ones;
 //   * a 16-byte LDS read feeds four MFMAs: the lane quarter q holds k = 4q..4q+3 of a 16-channel group, MFMA m takes element m of both
 //     operands (a permutation of k inside the group -- the same on both sides);
 //   * LDS images are XOR-swizzled like the other kernels' (weights: 16-byte column ^ ((row >> 1) & 7), applied on the DMA source
@@ -40,53 +41,81 @@ struct C64Frag {
   int pix, q;         // lane's pixel (0..15) and quarter (0..3)
 };
 
+// The K-steps run in four groups [0,2) [2,6) [6,12) [12,18): one `s_waitcnt vmcnt` + barrier at the START of a group (everything issued
+// before the group's last tile has arrived: two DMA instructions per later tile), none inside -- the whole image (153 KB, shared by
+// the branch's workgroups in L2) lands within 1.3 us of kernel entry (scripts/probes/lds_fill.hip), and a barrier + LDS round trip
+// per 256-cycle K-step cost more than the overlap it bought (EXPERIMENTS item 50).
+__host__ __device__ constexpr int c64_group_end(int ks) { return ks == 0 ? 2 : ks == 2 ? 6 : ks == 6 ? 12 : ks == 12 ? 18 : 0; }
+
+struct C64Ops {
+  float4 x0, x1, w0, w1;
+};
+
 template <int KS>
-__device__ __forceinline__ void c64_kstep(const C64Frag& f, f32x4& acc0, f32x4& acc1) {
-  // everything issued before weight tile KS + 1 has arrived (the patch and tiles 0..KS): two DMA instructions per later tile
-  wait_vm<2 * (C64_KSTEPS - 1 - KS)>();
-  __syncthreads();
+__device__ __forceinline__ void c64_sync() {
+  if constexpr (c64_group_end(KS) > 0) {
+    wait_vm<2 * (C64_KSTEPS - c64_group_end(KS))>();
+    __syncthreads();
+  }
+}
+
+template <int KS>
+__device__ __forceinline__ void c64_load(const C64Frag& f, C64Ops& o) {
   constexpr int ch = KS / 9, tap = KS % 9, r = tap / 3, s = tap % 3;
   const int pp = ((f.pix >> 2) + r) * 6 + (f.pix & 3) + s;            // patch pixel of this lane's output pixel under tap (r, s)
   const float* px = f.smem + pp * 64 + ch * 32;
   const float* wt = f.smem + C64_PATCH_FLOATS + KS * C64_TILE_FLOATS;
   const int sw = pp & 7;
-  const float4 x0 = *reinterpret_cast<const float4*>(px + ((f.q ^ sw) << 2));
-  const float4 x1 = *reinterpret_cast<const float4*>(px + (((4 + f.q) ^ sw) << 2));
-  const float4 w0 = *reinterpret_cast<const float4*>(wt + f.wrow_off[0]);
-  const float4 w1 = *reinterpret_cast<const float4*>(wt + f.wrow_off[1]);
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, x0.x, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, x1.x, acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, x0.y, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, x1.y, acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, x0.z, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, x1.z, acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, x0.w, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, x1.w, acc1, 0, 0, 0);
+  o.x0 = *reinterpret_cast<const float4*>(px + ((f.q ^ sw) << 2));
+  o.x1 = *reinterpret_cast<const float4*>(px + (((4 + f.q) ^ sw) << 2));
+  o.w0 = *reinterpret_cast<const float4*>(wt + f.wrow_off[0]);
+  o.w1 = *reinterpret_cast<const float4*>(wt + f.wrow_off[1]);
 }
 
+__device__ __forceinline__ void c64_mma(const C64Ops& o, f32x4& acc0, f32x4& acc1) {
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.x, o.x0.x, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.x, o.x1.x, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.y, o.x0.y, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.y, o.x1.y, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.z, o.x0.z, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.z, o.x1.z, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.w, o.x0.w, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.w, o.x1.w, acc1, 0, 0, 0);
+}
+
+// K-step KS: the operands of KS + 1 are read before the MFMAs of KS are issued (sched_barrier pins the order; the scheduler would
+// sink the reads to their use)
 template <int KS>
 struct C64Run {
-  static __device__ __forceinline__ void go(const C64Frag& f, f32x4& a0, f32x4& a1) {
-    C64Run<KS - 1>::go(f, a0, a1);
-    c64_kstep<KS>(f, a0, a1);
+  static __device__ __forceinline__ void go(const C64Frag& f, C64Ops& o0, C64Ops& o1, f32x4& a0, f32x4& a1) {
+    C64Run<KS - 1>::go(f, o0, o1, a0, a1);
+    if constexpr (KS + 1 < C64_KSTEPS) {
+      c64_sync<KS + 1>();
+      c64_load<KS + 1>(f, (KS & 1) ? o0 : o1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    c64_mma((KS & 1) ? o1 : o0, a0, a1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 };
 template <>
 struct C64Run<-1> {
-  static __device__ __forceinline__ void go(const C64Frag&, f32x4&, f32x4&) {}
+  static __device__ __forceinline__ void go(const C64Frag& f, C64Ops& o0, C64Ops&, f32x4&, f32x4&) {
+    c64_sync<0>();
+    c64_load<0>(f, o0);
+  }
 };
 
-// grid: groups * n * 121 workgroups of 256 threads; EPI 0 = bias + ReLU, 1 = bias + residual + ReLU
+// grid: (121 tiles, n images, groups) workgroups of 256 threads (no division by a run-time value in the index arithmetic: this
+// kernel lives for 4 us); EPI 0 = bias + ReLU, 1 = bias + residual + ReLU
 template <int EPI>
-__global__ __launch_bounds__(256, 1) void conv64_small_kernel(const ConvArgs a, int n) {
+__global__ __launch_bounds__(256, 1) void conv64_small_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int TPI = 121;                              // 11 x 11 tiles of 4 x 4 outputs per 44 x 44 image
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x;
-  const int tile = b % TPI, img = (b / TPI) % n, g = b / (TPI * n);
+  const int tile = blockIdx.x, img = blockIdx.y, g = blockIdx.z;
   const int ty = tile / 11, tx = tile - ty * 11;
-  const int Wp = a.W + 2;                               // 46
+  constexpr int Wp = S2 + 2;                            // 46
   const float* __restrict__ in = a.in + (size_t)g * a.in_gs + ((size_t)(img * Wp + ty * 4) * Wp + tx * 4) * a.in_ld;   // patch origin (padded)
   const float* __restrict__ wgt = a.w + (size_t)g * a.w_gs;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
@@ -125,7 +154,8 @@ __global__ __launch_bounds__(256, 1) void conv64_small_kernel(const ConvArgs a, 
     f.wrow_off[1] = row * 32 + (((4 + f.q) ^ sw) << 2);
   }
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  C64Run<C64_KSTEPS - 1>::go(f, acc0, acc1);
+  C64Ops o0, o1;
+  C64Run<C64_KSTEPS - 1>::go(f, o0, o1, acc0, acc1);
 
   // ---- epilogue: this lane = pixel (lane & 15), couts 16 wid + 4 (lane >> 4) .. + 3
   const int c = wid * 16 + (lane >> 4) * 4;
@@ -150,9 +180,9 @@ hipError_t launch_conv64_small(const ConvArgs& a, int n, int epi, hipStream_t st
     if (e != hipSuccess) return e;
     if (done) *done = true;
   }
-  const int grid = a.groups * n * 121;
-  if (epi == 1) hipLaunchKernelGGL(k1, dim3(grid), dim3(256), C64_LDS_BYTES, st, a, n);
-  else hipLaunchKernelGGL(k0, dim3(grid), dim3(256), C64_LDS_BYTES, st, a, n);
+  const dim3 grid(121, n, a.groups);
+  if (epi == 1) hipLaunchKernelGGL(k1, grid, dim3(256), C64_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(k0, grid, dim3(256), C64_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 

@@ -17,8 +17,8 @@
 //   * taps share the input: the rows of the (zero-bordered) input under the tile are fetched ONCE as they lie -- a contiguous run of
 //     padded rows, 128 bytes (32 channels) per pixel -- and every tap reads them at its own offset; the weights are the packed
 //     panels as they are ([chunk][tap][cout][32]: a K-step's 32 x 32 tile is 4 KB contiguous);
-//   * every byte is requested up front with LDS-DMA (patch, then the nine weight tiles in tap order, per 32-channel chunk); K-step
-//     (chunk, tap) starts after `s_waitcnt vmcnt(what was issued after its tile)` + barrier;
+//   * every byte is requested up front with LDS-DMA (patch, then the nine weight tiles in tap order, per 32-channel chunk); the K-steps
+//     run in groups that start with `s_waitcnt vmcnt(what was issued after the group's last tile)` + barrier;
 //   * v_mfma_f32_32x32x2_f32, A operand = weights, B operand = pixels: wave w = pixels 32 w .. 32 w + 31 of the tile x the 32 couts;
 //     a 16-byte LDS read feeds four MFMAs (lane half h holds channels 8 g + 4 h .. + 3 of an 8-channel group, MFMA e takes element e
 //     of both operands); two accumulators (even / odd groups) are added at the end;
@@ -27,6 +27,19 @@
 #include "mfma_common.h"
 
 namespace se3tn {
+
+// -DSE3TN_SMALL_TRACE (developer build, scripts/small_trace.py): thread 0 of every workgroup stamps wall_clock64() (100 MHz) at the
+// kernel's phase boundaries; the last launch's stamps are read back with se3tn_debug_trace_slices()
+#if defined(SE3TN_SMALL_TRACE)
+static __device__ unsigned long long g_cs_trace[1024][8];
+#define CS_TRACE(P)                                                                                      \
+  {                                                                                                      \
+    const unsigned lb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                 \
+    if (threadIdx.x == 0 && lb_ < 1024) g_cs_trace[lb_][P] = wall_clock64();                             \
+  }
+#else
+#define CS_TRACE(P)
+#endif
 
 template <int N>
 __device__ __forceinline__ void cs_wait_vm() {
@@ -38,6 +51,7 @@ struct CsGeom {
   static constexpr int NB = (PPMAX * 8 + 255) / 256;          // patch DMA instructions per thread and chunk
   static constexpr int PER_CHUNK = NB + 9;                    // + one per weight tile
   static constexpr int TOTAL = CHUNKS * PER_CHUNK;
+  static constexpr int NSTEPS = CHUNKS * 9;
   static constexpr int PATCH_FLOATS = NB * 256 * 4;
   static constexpr int CHUNK_FLOATS = PATCH_FLOATS + 9 * 1024;
   static constexpr size_t LDS = (size_t)CHUNKS * CHUNK_FLOATS * sizeof(float);
@@ -49,67 +63,102 @@ struct CsLane {
   int ppb, Wp;      // patch pixel under tap (0, 0) of this lane's output pixel; padded input width
 };
 
+// K-steps run in groups [0,1) [1,4) [4,9) [9,18): wait + barrier at the start of a group only (the DMA stream delivers a 4 KB weight
+// tile every ~0.1 us, a K-step computes for 0.43 us: after the first steps everything a group needs has long landed, and a barrier
+// + LDS round trip per K-step is a bubble the matrix pipe cannot hide with one wave per SIMD)
+__host__ __device__ constexpr int cs_group_end(int ks) { return ks == 0 ? 1 : ks == 1 ? 4 : ks == 4 ? 9 : ks == 9 ? 18 : 0; }
+
+struct CsFrag {
+  float4 x[4], w[4];   // B (pixels) and A (weights) fragments of one K-step: four 8-channel groups
+};
+
 template <class G, int KS>
-__device__ __forceinline__ void cs_kstep(const CsLane& f, f32x16& acc0, f32x16& acc1) {
-  constexpr int c = KS / 9, tap = KS % 9, r = tap / 3, s = tap % 3;
-  cs_wait_vm<G::TOTAL - (c * G::PER_CHUNK + G::NB + tap + 1)>();     // everything up to this K-step's weight tile has landed
-  __syncthreads();
-  const int pp = f.ppb + r * f.Wp + s;
-  const float* px = f.smem + c * G::CHUNK_FLOATS + pp * 32;
-  const float* wt = f.smem + c * G::CHUNK_FLOATS + G::PATCH_FLOATS + tap * 1024 + f.row * 32;
-  const int swp = (pp >> 1) & 7, sww = (f.row >> 1) & 7;
-  float4 x[4], w[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    x[g] = *reinterpret_cast<const float4*>(px + (((2 * g + f.kh) ^ swp) << 2));
-    w[g] = *reinterpret_cast<const float4*>(wt + (((2 * g + f.kh) ^ sww) << 2));
-  }
-#pragma unroll
-  for (int g = 0; g < 4; g += 2) {
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g].x, x[g].x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g + 1].x, x[g + 1].x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g].y, x[g].y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g + 1].y, x[g + 1].y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g].z, x[g].z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g + 1].z, x[g + 1].z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g].w, x[g].w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g + 1].w, x[g + 1].w, acc1, 0, 0, 0);
+__device__ __forceinline__ void cs_sync() {
+  if constexpr (cs_group_end(KS) > 0) {
+    constexpr int last = cs_group_end(KS) - 1, lc = last / 9, lt = last % 9;
+    cs_wait_vm<G::TOTAL - (lc * G::PER_CHUNK + G::NB + lt + 1)>();   // everything up to the group's last weight tile has landed
+    __syncthreads();
   }
 }
 
 template <class G, int KS>
+__device__ __forceinline__ void cs_load(const CsLane& f, CsFrag& fr) {
+  constexpr int c = KS / 9, tap = KS % 9, r = tap / 3, s = tap % 3;
+  const int pp = f.ppb + r * f.Wp + s;
+  const float* px = f.smem + c * G::CHUNK_FLOATS + pp * 32;
+  const float* wt = f.smem + c * G::CHUNK_FLOATS + G::PATCH_FLOATS + tap * 1024 + f.row * 32;
+  const int swp = (pp >> 1) & 7, sww = (f.row >> 1) & 7;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    fr.x[g] = *reinterpret_cast<const float4*>(px + (((2 * g + f.kh) ^ swp) << 2));
+    fr.w[g] = *reinterpret_cast<const float4*>(wt + (((2 * g + f.kh) ^ sww) << 2));
+  }
+}
+
+__device__ __forceinline__ void cs_mma(const CsFrag& fr, f32x16& acc0, f32x16& acc1) {
+#pragma unroll
+  for (int g = 0; g < 4; g += 2) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].x, fr.x[g].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].x, fr.x[g + 1].x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].y, fr.x[g].y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].y, fr.x[g + 1].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].z, fr.x[g].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].z, fr.x[g + 1].z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].w, fr.x[g].w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].w, fr.x[g + 1].w, acc1, 0, 0, 0);
+  }
+}
+
+// K-step KS: the fragments of KS + 1 are read (after its group's wait + barrier, if it starts one) BEFORE the 16 MFMAs of KS are
+// issued -- a K-step of matrix work (1,024 cycles) between an LDS read and its use.  sched_barrier pins that order: left to itself
+// the scheduler sinks the reads to one MFMA before their use (64 cycles, less than an LDS round trip: measured, EXPERIMENTS item 50)
+template <class G, int KS>
 struct CsRun {
-  static __device__ __forceinline__ void go(const CsLane& f, f32x16& a0, f32x16& a1) {
-    CsRun<G, KS - 1>::go(f, a0, a1);
-    cs_kstep<G, KS>(f, a0, a1);
+  static __device__ __forceinline__ void go(const CsLane& f, CsFrag& fr0, CsFrag& fr1, f32x16& a0, f32x16& a1) {
+    CsRun<G, KS - 1>::go(f, fr0, fr1, a0, a1);
+    if constexpr (KS + 1 < G::NSTEPS) {
+      cs_sync<G, KS + 1>();
+      cs_load<G, KS + 1>(f, (KS & 1) ? fr0 : fr1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cs_mma((KS & 1) ? fr1 : fr0, a0, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (KS == 3) { CS_TRACE(3) }
+    if (KS == 8) { CS_TRACE(4) }
   }
 };
 template <class G>
 struct CsRun<G, -1> {
-  static __device__ __forceinline__ void go(const CsLane&, f32x16&, f32x16&) {}
+  static __device__ __forceinline__ void go(const CsLane& f, CsFrag& fr0, CsFrag&, f32x16&, f32x16&) {
+    cs_sync<G, 0>();
+    CS_TRACE(2)
+    cs_load<G, 0>(f, fr0);
+  }
 };
 
-// grid: groups x images x m-tiles x n-tiles x slices workgroups of 256 threads (the slice is the fastest index: blockIdx % 8 is the XCD
-// a workgroup lands on, so the workgroups that read the same input channels share an L2).  ConvArgs: tiles_n = cout / 32, slices set.
-template <int CHUNKS, int STRIDE, int PPMAX>
-__global__ __launch_bounds__(256, 1) void conv_slices_small_kernel(const ConvArgs a, int tpi) {
+// grid: (slices x n-tiles, m-tiles x images, groups) workgroups of 256 threads; the slice is the fastest index: consecutive
+// workgroups go to consecutive XCDs, so the workgroups that read the same input channels share an L2.  Everything about the
+// layer's geometry is a template constant: the index arithmetic of a kernel whose whole life is 12 us must not contain a division by
+// a run-time value (the first version spent 2.6 us between entry and its last DMA issue: EXPERIMENTS item 50).
+// The partial sums go to conv_reduce_kernel (next launch).  Measured alternative (EXPERIMENTS item 50): the reduction in THIS launch
+// -- partial tiles written through to memory with sc1 stores, a ticket per output tile, the last arriver reads the SLICES tiles back
+// with sc1 loads, adds them in slice order and applies the epilogue: 210 us per forward against 183 us with the separate launch.
+// Three dependent round trips to the memory side (store acknowledgements, ticket, read-back) cost more than a launch boundary.
+template <int CHUNKS, int STRIDE, int PPMAX, int WO, int SLICES, int NT>
+__global__ __launch_bounds__(256, 1) void conv_slices_small_kernel(const ConvArgs a) {
   using G = CsGeom<CHUNKS, PPMAX>;
+  constexpr int HW = WO * WO, TPI = (HW + 127) / 128, H = STRIDE * WO, Wp = H + 2, cout = NT * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  CS_TRACE(0)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int b = blockIdx.x;
-  const int sl = b % a.slices; b /= a.slices;
-  const int nt = b % a.tiles_n; b /= a.tiles_n;
-  const int HW = a.Ho * a.Wo, nimg = a.M / HW;
-  const int mt = b % (tpi * nimg), g = b / (tpi * nimg);
-  const int img = mt / tpi, t = mt - img * tpi;
-  const int Wp = a.W + 2;
+  const int sl = blockIdx.x % SLICES, nt = blockIdx.x / SLICES;
+  const int img = blockIdx.y / TPI, t = blockIdx.y % TPI, g = blockIdx.z;
   const int m0 = t * 128, m1 = min(m0 + 127, HW - 1);
-  const int oy0 = m0 / a.Wo, oy1 = m1 / a.Wo;
+  const int oy0 = m0 / WO, oy1 = m1 / WO;
   const int PP = ((oy1 - oy0) * STRIDE + 3) * Wp;           // pixels of the patch: whole padded rows oy0 * STRIDE .. oy1 * STRIDE + 2
-  const size_t pix0 = ((size_t)img * (a.H + 2) + (size_t)oy0 * STRIDE) * Wp;
+  const size_t pix0 = ((size_t)img * (H + 2) + (size_t)oy0 * STRIDE) * Wp;
   const float* __restrict__ in = a.in + (size_t)g * a.in_gs + pix0 * a.in_ld + (size_t)sl * CHUNKS * 32;
-  const int cout = a.tiles_n * 32;
   // panels [chunk][tap][cout][32] of group g; this workgroup's rows nt * 32 .. + 31 of chunks sl * CHUNKS ..
   const float* __restrict__ wgt = a.w + (size_t)g * a.w_gs + ((size_t)sl * CHUNKS * 9 * cout + (size_t)nt * 32) * 32;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
@@ -133,42 +182,66 @@ __global__ __launch_bounds__(256, 1) void conv_slices_small_kernel(const ConvArg
                 lds0 + (unsigned)((c * G::CHUNK_FLOATS + G::PATCH_FLOATS + tap * 1024 + wid * 256) * 4));
   }
 
+  CS_TRACE(1)
   CsLane f;
   f.smem = smem;
   f.row = lane & 31;
   f.kh = lane >> 5;
   f.Wp = Wp;
   const int m = min(m0 + wid * 32 + f.row, HW - 1);         // (rows past the image compute its last pixel again and are not stored)
-  const int oy = m / a.Wo, ox = m - oy * a.Wo;
+  const int oy = m / WO, ox = m - oy * WO;
   f.ppb = (oy - oy0) * STRIDE * Wp + ox * STRIDE;
   f32x16 acc0, acc1;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-  CsRun<G, CHUNKS * 9 - 1>::go(f, acc0, acc1);
+  CsFrag fr0, fr1;
+  CsRun<G, CHUNKS * 9 - 1>::go(f, fr0, fr1, acc0, acc1);
 
-  // raw partial sums: part[slice][group][m][cout] (conv_reduce_kernel); this lane = pixel (lane & 31), couts 8 q + 4 kh .. + 3
-  if (m0 + wid * 32 + f.row < HW) {
-    float* __restrict__ part = a.part + (((size_t)sl * a.groups + g) * a.M + (size_t)img * HW + m) * cout + nt * 32 + f.kh * 4;
+#if defined(SE3TN_SMALL_TRACE)
+  if (acc0[0] + acc1[0] == 1.2345e-30f) return;   // (the accumulators are final before the stamp)
+#endif
+  CS_TRACE(5)
+  // partial sums: part[slice][group][m][cout] (conv_reduce_kernel's layout); this lane = pixel (lane & 31), couts 8 q + 4 kh .. + 3
+  const bool valid = m0 + wid * 32 + f.row < HW;
+  const size_t slice_stride = (size_t)a.groups * a.M * cout;
+  float* __restrict__ part0 = a.part + (((size_t)g * a.M + (size_t)img * HW + m) * cout + nt * 32 + f.kh * 4);
+  float4 mine[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<float4*>(part + q * 8) = make_float4(acc0[4 * q + 0] + acc1[4 * q + 0], acc0[4 * q + 1] + acc1[4 * q + 1],
-                                                             acc0[4 * q + 2] + acc1[4 * q + 2], acc0[4 * q + 3] + acc1[4 * q + 3]);
+  for (int q = 0; q < 4; ++q)
+    mine[q] = make_float4(acc0[4 * q + 0] + acc1[4 * q + 0], acc0[4 * q + 1] + acc1[4 * q + 1], acc0[4 * q + 2] + acc1[4 * q + 2],
+                          acc0[4 * q + 3] + acc1[4 * q + 3]);
+  if (valid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(part0 + sl * slice_stride + q * 8) = mine[q];
   }
+#if defined(SE3TN_SMALL_TRACE)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  CS_TRACE(6)
 }
 
-template <int CHUNKS, int STRIDE, int PPMAX>
-static hipError_t launch_cs(const ConvArgs& a, int tpi, int grid, hipStream_t st) {
+#if defined(SE3TN_SMALL_TRACE)
+extern "C" int se3tn_debug_trace_slices(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_trace), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
+
+template <int CHUNKS, int STRIDE, int PPMAX, int WO, int SLICES, int NT>
+static hipError_t launch_cs(const ConvArgs& a, hipStream_t st) {
   using G = CsGeom<CHUNKS, PPMAX>;
   static_assert(G::LDS <= 160 * 1024 && G::TOTAL <= 63, "LDS image / DMA count out of range");
+  constexpr int HW = WO * WO, TPI = (HW + 127) / 128;
+  if (a.Ho != WO || a.Wo != WO || a.H != STRIDE * WO || a.W != STRIDE * WO || a.tiles_n != NT || a.slices != SLICES || a.M % HW != 0)
+    return hipErrorInvalidValue;
   static PerDeviceOnce attr;
-  auto kern = conv_slices_small_kernel<CHUNKS, STRIDE, PPMAX>;
+  auto kern = conv_slices_small_kernel<CHUNKS, STRIDE, PPMAX, WO, SLICES, NT>;
   bool* done = attr.current();
   if (!(done && *done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     if (e != hipSuccess) return e;
     if (done) *done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS, st, a, tpi);
+  hipLaunchKernelGGL(kern, dim3(SLICES * NT, TPI * (a.M / HW), a.groups), dim3(256), G::LDS, st, a);
   return hipGetLastError();
 }
 
@@ -183,12 +256,10 @@ int conv_slices_small_count(int cin, int stride, int H) {
 
 // the conv part only: a.slices / a.tiles_n (= cout / 32) are set by the caller, who also launches the reduction
 hipError_t launch_conv_slices_small(const ConvArgs& a, int cin, int stride, hipStream_t st) {
-  const int HW = a.Ho * a.Wo, tpi = (HW + 127) / 128, nimg = a.M / HW;
-  const int grid = a.groups * nimg * tpi * a.tiles_n * a.slices;
-  if (cin == 128 && stride == 2) return launch_cs<1, 2, 690>(a, tpi, grid, st);
-  if (cin == 256 && stride == 1) return launch_cs<1, 1, 216>(a, tpi, grid, st);
-  if (cin == 256 && stride == 2) return launch_cs<1, 2, 552>(a, tpi, grid, st);
-  if (cin == 512 && stride == 1) return launch_cs<2, 1, 169>(a, tpi, grid, st);
+  if (cin == 128 && stride == 2) return launch_cs<1, 2, 690, S3, 4, 8>(a, st);     // convAB1: 128 -> 256
+  if (cin == 256 && stride == 1) return launch_cs<1, 1, 216, S3, 8, 8>(a, st);     // convAB2: 256 -> 256
+  if (cin == 256 && stride == 2) return launch_cs<1, 2, 552, S4, 8, 32>(a, st);    // trans|rot conv1: 256 -> 1024
+  if (cin == 512 && stride == 1) return launch_cs<2, 1, 169, S4, 8, 16>(a, st);    // trans|rot conv2: 2 x (512 -> 512)
   return hipErrorInvalidValue;
 }
 

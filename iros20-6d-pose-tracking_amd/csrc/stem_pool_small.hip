@@ -37,19 +37,40 @@ struct StemPoolArgs {
 __host__ __device__ constexpr int sp_tap_r(int e) { return e < 42 ? (e >> 1) / 3 : (e < 48 ? 2 * ((e >> 1) - 21) + (e & 1) : 6); }
 __host__ __device__ constexpr int sp_tap_s(int e) { return e < 42 ? 2 * ((e >> 1) % 3) + (e & 1) : 6; }
 
-template <int E>
-struct SpTaps {
-  static __device__ __forceinline__ void go(const float (&w)[49], const float* p0, const float* p1, f32x4& a0, f32x4& a1) {
-    SpTaps<E - 1>::go(w, p0, p1, a0, a1);
-    constexpr int off = (sp_tap_r(E) * SP_PW + sp_tap_s(E)) * 4;
-    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[E], p0[off], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[E], p1[off], a1, 0, 0, 0);
+// the 49 taps' B operands of two pixel blocks: one 4-byte LDS read each, at a compile-time offset from the lane's patch address.
+// ALL of a block pair's reads are issued before its first MFMA (and the next pair's while this one computes): issued next to their
+// use, each pair of MFMAs waited for an LDS round trip (EXPERIMENTS item 50: 14.2 us -> see there)
+struct SpOperands {
+  float x0[49], x1[49];
+};
+__device__ __forceinline__ void sp_load(SpOperands& o, const float* p0, const float* p1) {
+#pragma unroll
+  for (int e = 0; e < 49; ++e) {
+    const int off = (sp_tap_r(e) * SP_PW + sp_tap_s(e)) * 4;
+    o.x0[e] = p0[off];
+    o.x1[e] = p1[off];
   }
-};
-template <>
-struct SpTaps<-1> {
-  static __device__ __forceinline__ void go(const float (&)[49], const float*, const float*, f32x4&, f32x4&) {}
-};
+}
+// the MFMAs of one block pair, with the NEXT pair's operand reads interleaved one tap at a time and the PREVIOUS pair's bias + SELU
+// (eight expm1f per lane: ~0.9 us of vector work per pair) spread over the first eight taps -- vector instructions issue while
+// the matrix pipe works.  sched_barrier pins the order: left to itself the scheduler sinks every read to its use.
+template <bool PREFETCH, bool EPI>
+__device__ __forceinline__ void sp_mma(const float (&w)[49], const SpOperands& o, SpOperands& nxt, const float* n0, const float* n1,
+                                       f32x4& a0, f32x4& a1, const f32x4& p0, const f32x4& p1, const float4& bias, float (&ov)[8]) {
+  const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+  for (int e = 0; e < 49; ++e) {
+    if (PREFETCH) {
+      const int off = (sp_tap_r(e) * SP_PW + sp_tap_s(e)) * 4;
+      nxt.x0[e] = n0[off];
+      nxt.x1[e] = n1[off];
+    }
+    if (EPI && e < 8) ov[e] = selu_f((e < 4 ? p0[e & 3] : p1[e & 3]) + bv[e & 3]);
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], o.x0[e], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], o.x1[e], a1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
 __global__ __launch_bounds__(256) void stem_pool_small_kernel(const StemPoolArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SP_PATCH_BYTES + 81 * 64 * 4];
@@ -57,8 +78,7 @@ __global__ __launch_bounds__(256) void stem_pool_small_kernel(const StemPoolArgs
   float* stile = reinterpret_cast<float*>(smem + SP_PATCH_BYTES);     // [81 stem pixels][64 couts]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x;
-  const int tile = b % 121, img = (b / 121) % a.n, br = b / (121 * a.n);
+  const int tile = blockIdx.x, img = blockIdx.y, br = blockIdx.z;
   const int ti = tile / 11, tj = tile - ti * 11;
   const int R0 = ti == 0 ? 0 : 8 * ti - 1, C0 = tj == 0 ? 0 : 8 * tj - 1;   // first stem row / column of the 9 x 9 window
   const float* __restrict__ in = a.in[br] + ((size_t)img * SP_IP * SP_IP + (size_t)(2 * R0) * SP_IP + 2 * C0) * 4;
@@ -85,22 +105,40 @@ __global__ __launch_bounds__(256) void stem_pool_small_kernel(const StemPoolArgs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ---- 6 blocks of 16 stem pixels, two at a time
+  // ---- 6 blocks of 16 stem pixels, two at a time; the operands of pair i + 1 are read while pair i computes
   const int kk = lane >> 4;
-#pragma unroll 1
-  for (int pb = 0; pb < 6; pb += 2) {
-    const int p0 = min(pb * 16 + (lane & 15), 80), p1 = min(pb * 16 + 16 + (lane & 15), 80);
-    const float* a0p = patch + ((2 * (p0 / 9)) * SP_PW + 2 * (p0 % 9)) * 4 + kk;
-    const float* a1p = patch + ((2 * (p1 / 9)) * SP_PW + 2 * (p1 % 9)) * 4 + kk;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    SpTaps<48>::go(w, a0p, a1p, acc0, acc1);
-    const int q0 = pb * 16 + (lane & 15), q1 = q0 + 16;
-    if (q0 < 81)
-      *reinterpret_cast<float4*>(stile + q0 * 64 + c) =
-          make_float4(selu_f(acc0[0] + bias.x), selu_f(acc0[1] + bias.y), selu_f(acc0[2] + bias.z), selu_f(acc0[3] + bias.w));
-    if (q1 < 81)
-      *reinterpret_cast<float4*>(stile + q1 * 64 + c) =
-          make_float4(selu_f(acc1[0] + bias.x), selu_f(acc1[1] + bias.y), selu_f(acc1[2] + bias.z), selu_f(acc1[3] + bias.w));
+  auto patch_ptr = [&](int blk) -> const float* {
+    const int p = min(blk * 16 + (lane & 15), 80);
+    return patch + ((2 * (p / 9)) * SP_PW + 2 * (p % 9)) * 4 + kk;
+  };
+  SpOperands ops[2];
+  sp_load(ops[0], patch_ptr(0), patch_ptr(1));
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc[3][2];
+  float ov[8];
+  auto store_pair = [&](int it) {             // bias + SELU of pair `it` is in ov: the two pixels' four couts each
+    const int q0 = it * 32 + (lane & 15), q1 = q0 + 16;
+    if (q0 < 81) *reinterpret_cast<float4*>(stile + q0 * 64 + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    if (q1 < 81) *reinterpret_cast<float4*>(stile + q1 * 64 + c) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+  };
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int pb = 2 * it;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[it][0][e] = 0.f; acc[it][1][e] = 0.f; }
+    if (it == 0)
+      sp_mma<true, false>(w, ops[0], ops[1], patch_ptr(2), patch_ptr(3), acc[0][0], acc[0][1], acc[0][0], acc[0][1], bias, ov);
+    else if (it == 1)
+      sp_mma<true, true>(w, ops[1], ops[0], patch_ptr(pb + 2), patch_ptr(pb + 3), acc[1][0], acc[1][1], acc[0][0], acc[0][1], bias, ov);
+    else
+      sp_mma<false, true>(w, ops[0], ops[0], nullptr, nullptr, acc[2][0], acc[2][1], acc[1][0], acc[1][1], bias, ov);
+    if (it > 0) store_pair(it - 1);
+  }
+  {
+    const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ov[e] = selu_f((e < 4 ? acc[2][0][e & 3] : acc[2][1][e & 3]) + bv[e & 3]);
+    store_pair(2);
   }
   __syncthreads();
 
@@ -129,7 +167,7 @@ hipError_t launch_stem_pool_small(const float* inA, const float* inB, const floa
                                   hipStream_t st) {
   StemPoolArgs a;
   a.in[0] = inA; a.in[1] = inB; a.w = w; a.bias = bias; a.pool = pool; a.n = n;
-  hipLaunchKernelGGL(stem_pool_small_kernel, dim3(2 * n * 121), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(stem_pool_small_kernel, dim3(121, n, 2), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
