@@ -72,7 +72,7 @@ struct se3tn_ctx {
   bool wino_fuse = true;                        // whole residual blocks as one fused launch sequence (SE3TN_WINOGRAD_FUSE=0: conv by conv)
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
   int* splitk_sem = nullptr;                    // [2 x SE3TN_SPLITK_MAX_TILES] arrival / seen counters of the fused split-K reduction (zero between launches)
-  bool small_kernels = true;                    // SE3TN_SMALL_KERNELS=0 (developer switch): batch 1-2 through the split-K kernels only
+  bool small_kernels = true;                    // SE3TN_SMALL_KERNELS=0 (developer switch): batch 1-5 through the split-K kernels only
   bool splitk_fused = false;                    // SE3TN_SPLITK_FUSED=1 (developer switch): the reduction inside the split-K launch -- bitwise the same results,
                                                 // but SLOWER on this chip (363 vs 268 us per batch-1 forward: EXPERIMENTS item 41), so off
   size_t part_bytes = 0;

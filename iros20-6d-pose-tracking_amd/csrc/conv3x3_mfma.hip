@@ -840,7 +840,8 @@ static int pick_slices(const ConvArgs& a, int cin, int cout, int big_tile_rows, 
 //   255 + 2 per row break + (2 Wp + 2) per image break + 2 (Wp + 1) + 1     (tests/test_slab_geometry.py)
 //   W = 44: 454 -> 464     W = 22: 378 -> 384     W = 11: 410 -> 424
 #ifndef SE3TN_CONV64_SMALL_MAX_N
-#define SE3TN_CONV64_SMALL_MAX_N 2   // the trunk convs of up to this many pairs take conv64_small_kernel (0: never)
+#define SE3TN_CONV64_SMALL_MAX_N 5   // the trunk convs of up to this many pairs take conv64_small_kernel (0: never).  Measured 2 vs 5:
+                                     // 8.6k -> 9.6k / 10.2k -> 11.0k / 10.8k -> 11.2k pairs/s at 3 / 4 / 5 pairs (one stream)
 #endif
 #ifndef SE3TN_SLICES_SMALL_MAX_N
 #define SE3TN_SLICES_SMALL_MAX_N 5   // up to this many pairs the 128 .. 512-channel convs take conv_slices_small_kernel (0: never)

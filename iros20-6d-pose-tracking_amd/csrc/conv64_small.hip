@@ -1,5 +1,5 @@
 // The 64 -> 64, 3x3, stride-1 convs of the trunk (ResnetBasicBlock convA2 / convB2 / convB3, network_modules.py:86-120) at batch
-// 1-2: the regime Tracker.on_track runs in (predict.py:416: one pair per frame, frames serial).
+// 1-5: the regime Tracker.on_track runs in (predict.py:416: one pair per frame, frames serial).
 //
 // At one pair a trunk conv is 1,936 pixels x 64 couts x K = 576: 0.14 GFLOP, 1.8 us of the matrix cores -- and the split-K path
 // (conv3x3_splitk_kernel + conv_reduce_kernel) took 15-17 us for it: two launches, a 6 MB partial-sum round trip, three latency-bound
@@ -8,9 +8,9 @@
 // of its branch (18 K-steps x 8 KB = 144 KB, the packed panels as they are) and its 6 x 6 x 64 input patch (9 KB) in LDS.
 //   * matrix instruction: v_mfma_f32_16x16x4_f32 (exact float32, like the 32x32x2 form elsewhere); A operand = weights, B operand =
 //     pixels, so a lane ends with ONE pixel x 4 consecutive couts (float4 bias / residual / store);  wave w = couts 16w..16w+15;
-//   * every byte is requested up front: 3 + 36 LDS-DMA instructions per thread (patch, then the 18 weight tiles in K order); the
-//     K-steps run in four groups, each starting with `s_waitcnt vmcnt(what was issued after its last tile)` + barrier -- the matrix
-//     work of the early groups runs under the arrival of the late ones;
+//   * LDS-DMA: the patch and four weight tiles are requested before the first K-step, tile ks + 4 from between the MFMAs of K-step
+//     ks; K-step ks starts after `s_waitcnt vmcnt(what was requested after its tile)` + barrier, its operands are read one K-step
+//     ahead of their MFMAs;
 //   * a 16-byte LDS read feeds four MFMAs: the lane quarter q holds k = 4q..4q+3 of a 16-channel group, MFMA m takes element m of both
 //     operands (a permutation of k inside the group -- the same on both sides);
 //   * LDS images are XOR-swizzled like the other kernels' (weights: 16-byte column ^ ((row >> 1) & 7), applied on the DMA source
@@ -18,7 +18,7 @@
 //   * two accumulators (the two 16-channel groups of a K-step) are added at the end: 144 dependent MFMAs would wait on each other;
 //   * stored padding: the input carries its zero border, the patch is read without bounds logic; only interiors are stored.
 // Float32 only; the f16x3 mode keeps the split-K kernels.  Results differ from the split-K path in the last bits (another summation
-// order), are bitwise reproducible, and do not depend on the batch (n = 1 and n = 2 use the same tiles).
+// order), are bitwise reproducible, and do not depend on the batch (every n uses the same tiles).
 #include "mfma_common.h"
 
 namespace se3tn {
@@ -41,11 +41,30 @@ struct C64Frag {
   int pix, q;         // lane's pixel (0..15) and quarter (0..3)
 };
 
-// The K-steps run in four groups [0,2) [2,6) [6,12) [12,18): one `s_waitcnt vmcnt` + barrier at the START of a group (everything issued
-// before the group's last tile has arrived: two DMA instructions per later tile), none inside -- the whole image (153 KB, shared by
-// the branch's workgroups in L2) lands within 1.3 us of kernel entry (scripts/probes/lds_fill.hip), and a barrier + LDS round trip
-// per 256-cycle K-step cost more than the overlap it bought (EXPERIMENTS item 50).
-__host__ __device__ constexpr int c64_group_end(int ks) { return ks == 0 ? 2 : ks == 2 ? 6 : ks == 6 ? 12 : ks == 12 ? 18 : 0; }
+// DMA schedule: the patch and the first C64_AHEAD weight tiles are requested before the first K-step; K-step ks requests tile
+// ks + C64_AHEAD between its MFMAs (the issue of an LDS-DMA instruction blocks the wave for ~35 cycles while the four waves share the
+// address pipe: 153 KB issued up front kept the matrix pipe idle for 1.9 us of a 4 us kernel -- scripts/small_trace.py, EXPERIMENTS
+// item 50).  c64_outstanding(s) = DMA instructions issued AFTER tile s's two at the moment K-step s synchronises (in the body of
+// K-step s - 1, before that body's own request): what `s_waitcnt vmcnt` may leave in flight.
+constexpr int C64_AHEAD = 4;
+__host__ __device__ constexpr int c64_tiles_issued(int s) { return s == 0 ? C64_AHEAD : (s + C64_AHEAD - 1 < C64_KSTEPS ? s + C64_AHEAD - 1 : C64_KSTEPS); }
+__host__ __device__ constexpr int c64_outstanding(int s) { return 2 * (c64_tiles_issued(s) - (s + 1)); }
+__host__ __device__ constexpr bool c64_schedule_ok() {
+  for (int s = 0; s < C64_KSTEPS; ++s)
+    if (c64_outstanding(s) < 0) return false;
+  return true;
+}
+static_assert(c64_schedule_ok(), "a K-step would wait for a weight tile that has not been requested");
+
+struct C64Dma {        // this thread's part of a weight tile: 16 bytes of rows tid >> 3 and 32 + (tid >> 3)
+  const float* wgt;
+  unsigned wvoff, wl;
+};
+template <int KS>
+__device__ __forceinline__ void c64_request_tile(const C64Dma& d) {
+  glds16<0>(d.wgt + (size_t)KS * C64_TILE_FLOATS, d.wvoff, d.wl + (unsigned)(KS * C64_TILE_FLOATS * 4));
+  glds16<0>(d.wgt + (size_t)KS * C64_TILE_FLOATS + 1024, d.wvoff, d.wl + (unsigned)(KS * C64_TILE_FLOATS * 4 + 4096));
+}
 
 struct C64Ops {
   float4 x0, x1, w0, w1;
@@ -53,10 +72,8 @@ struct C64Ops {
 
 template <int KS>
 __device__ __forceinline__ void c64_sync() {
-  if constexpr (c64_group_end(KS) > 0) {
-    wait_vm<2 * (C64_KSTEPS - c64_group_end(KS))>();
-    __syncthreads();
-  }
+  wait_vm<c64_outstanding(KS)>();
+  __syncthreads();
 }
 
 template <int KS>
@@ -72,35 +89,41 @@ __device__ __forceinline__ void c64_load(const C64Frag& f, C64Ops& o) {
   o.w1 = *reinterpret_cast<const float4*>(wt + f.wrow_off[1]);
 }
 
+template <int HALF>
 __device__ __forceinline__ void c64_mma(const C64Ops& o, f32x4& acc0, f32x4& acc1) {
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.x, o.x0.x, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.x, o.x1.x, acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.y, o.x0.y, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.y, o.x1.y, acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.z, o.x0.z, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.z, o.x1.z, acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.w, o.x0.w, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.w, o.x1.w, acc1, 0, 0, 0);
+  if (HALF == 0) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.x, o.x0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.x, o.x1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.y, o.x0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.y, o.x1.y, acc1, 0, 0, 0);
+  } else {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.z, o.x0.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.z, o.x1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w0.w, o.x0.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w1.w, o.x1.w, acc1, 0, 0, 0);
+  }
 }
 
-// K-step KS: the operands of KS + 1 are read before the MFMAs of KS are issued (sched_barrier pins the order; the scheduler would
-// sink the reads to their use)
+// K-step KS: wait + barrier for tile KS + 1, its operands read, THEN the MFMAs of KS with the request for tile KS + C64_AHEAD in
+// their middle.  sched_barrier pins that order (the scheduler would sink the reads to their use).
 template <int KS>
 struct C64Run {
-  static __device__ __forceinline__ void go(const C64Frag& f, C64Ops& o0, C64Ops& o1, f32x4& a0, f32x4& a1) {
-    C64Run<KS - 1>::go(f, o0, o1, a0, a1);
+  static __device__ __forceinline__ void go(const C64Frag& f, const C64Dma& d, C64Ops& o0, C64Ops& o1, f32x4& a0, f32x4& a1) {
+    C64Run<KS - 1>::go(f, d, o0, o1, a0, a1);
     if constexpr (KS + 1 < C64_KSTEPS) {
       c64_sync<KS + 1>();
       c64_load<KS + 1>(f, (KS & 1) ? o0 : o1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    c64_mma((KS & 1) ? o1 : o0, a0, a1);
+    c64_mma<0>((KS & 1) ? o1 : o0, a0, a1);
+    if constexpr (KS + C64_AHEAD < C64_KSTEPS) c64_request_tile<KS + C64_AHEAD>(d);
+    c64_mma<1>((KS & 1) ? o1 : o0, a0, a1);
     __builtin_amdgcn_sched_barrier(0);
   }
 };
 template <>
 struct C64Run<-1> {
-  static __device__ __forceinline__ void go(const C64Frag& f, C64Ops& o0, C64Ops&, f32x4&, f32x4&) {
+  static __device__ __forceinline__ void go(const C64Frag& f, const C64Dma&, C64Ops& o0, C64Ops&, f32x4&, f32x4&) {
     c64_sync<0>();
     c64_load<0>(f, o0);
   }
@@ -131,18 +154,18 @@ __global__ __launch_bounds__(256, 1) void conv64_small_kernel(const ConvArgs a) 
     const unsigned voff = (unsigned)(((py * Wp + pxx) * a.in_ld + col * 4) * 4);
     glds16<0>(in, voff, lds0 + (unsigned)((j * 256 + wid * 64) * 16));
   }
-  // ... then the 18 weight tiles in K order (the packed panels [chunk][tap][64 couts][32]: 8 KB each, row r, column (tid & 7) ^ ((r >> 1) & 7))
+  // ... then the first weight tiles (the packed panels [chunk][tap][64 couts][32]: 8 KB each, row r, column (tid & 7) ^ ((r >> 1) & 7));
+  // the rest are requested from inside the K-steps
+  C64Dma dma;
   {
     const int r0 = tid >> 3;
     const int c4 = (tid & 7) ^ ((r0 >> 1) & 7);
-    const unsigned wvoff = (unsigned)((r0 * 32 + c4 * 4) * 4);
-    const unsigned wl = lds0 + (unsigned)(C64_PATCH_FLOATS * 4 + wid * 1024);
-#pragma unroll
-    for (int ks = 0; ks < C64_KSTEPS; ++ks) {
-      glds16<0>(wgt + (size_t)ks * C64_TILE_FLOATS, wvoff, wl + (unsigned)(ks * C64_TILE_FLOATS * 4));
-      glds16<0>(wgt + (size_t)ks * C64_TILE_FLOATS + 1024, wvoff, wl + (unsigned)(ks * C64_TILE_FLOATS * 4 + 4096));
-    }
+    dma.wgt = wgt;
+    dma.wvoff = (unsigned)((r0 * 32 + c4 * 4) * 4);
+    dma.wl = lds0 + (unsigned)(C64_PATCH_FLOATS * 4 + wid * 1024);
   }
+  c64_request_tile<0>(dma); c64_request_tile<1>(dma); c64_request_tile<2>(dma); c64_request_tile<3>(dma);
+  static_assert(C64_AHEAD == 4, "the prologue requests tiles 0 .. C64_AHEAD - 1");
 
   C64Frag f;
   f.smem = smem;
@@ -155,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void conv64_small_kernel(const ConvArgs a) 
   }
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   C64Ops o0, o1;
-  C64Run<C64_KSTEPS - 1>::go(f, o0, o1, acc0, acc1);
+  C64Run<C64_KSTEPS - 1>::go(f, dma, o0, o1, acc0, acc1);
 
   // ---- epilogue: this lane = pixel (lane & 15), couts 16 wid + 4 (lane >> 4) .. + 3
   const int c = wid * 16 + (lane >> 4) * 4;

@@ -17,8 +17,9 @@
 //   * taps share the input: the rows of the (zero-bordered) input under the tile are fetched ONCE as they lie -- a contiguous run of
 //     padded rows, 128 bytes (32 channels) per pixel -- and every tap reads them at its own offset; the weights are the packed
 //     panels as they are ([chunk][tap][cout][32]: a K-step's 32 x 32 tile is 4 KB contiguous);
-//   * every byte is requested up front with LDS-DMA (patch, then the nine weight tiles in tap order, per 32-channel chunk); the K-steps
-//     run in groups that start with `s_waitcnt vmcnt(what was issued after the group's last tile)` + barrier;
+//   * LDS-DMA (patch, then the nine weight tiles in tap order, per 32-channel chunk): the first patch and four tiles are requested
+//     before the first K-step, two more instructions from between the MFMAs of every K-step; a K-step starts after `s_waitcnt
+//     vmcnt(what was requested after its tile)` + barrier, and its operands are read one K-step ahead of their MFMAs;
 //   * v_mfma_f32_32x32x2_f32, A operand = weights, B operand = pixels: wave w = pixels 32 w .. 32 w + 31 of the tile x the 32 couts;
 //     a 16-byte LDS read feeds four MFMAs (lane half h holds channels 8 g + 4 h .. + 3 of an 8-channel group, MFMA e takes element e
 //     of both operands); two accumulators (even / odd groups) are added at the end;
@@ -52,6 +53,20 @@ struct CsGeom {
   static constexpr int PER_CHUNK = NB + 9;                    // + one per weight tile
   static constexpr int TOTAL = CHUNKS * PER_CHUNK;
   static constexpr int NSTEPS = CHUNKS * 9;
+  // DMA schedule (instruction index d: chunk d / PER_CHUNK; inside a chunk NB patch instructions, then the nine weight tiles):
+  // AHEAD = the first chunk's patch + its first four tiles are requested before the first K-step, every K-step requests RATE more
+  // from between its MFMAs.  (Issuing an LDS-DMA instruction blocks the wave ~35 cycles while the four waves share the address
+  // pipe: with all 30 up front the matrix pipe idled for the first 1.9 us -- scripts/small_trace.py, EXPERIMENTS item 50.)
+  static constexpr int AHEAD = NB + 4, RATE = 2;
+  static constexpr int issued_before(int ks) { return AHEAD + RATE * ks < TOTAL ? AHEAD + RATE * ks : TOTAL; }   // ... K-step ks's own requests
+  static constexpr int tile_index(int ks) { return (ks / 9) * PER_CHUNK + NB + ks % 9; }
+  // DMA instructions requested AFTER K-step s's weight tile when s synchronises (in the body of K-step s - 1, before its requests)
+  static constexpr int outstanding(int s) { return (s == 0 ? AHEAD : issued_before(s - 1)) - (tile_index(s) + 1); }
+  static constexpr bool schedule_ok() {
+    for (int s = 0; s < NSTEPS; ++s)
+      if (outstanding(s) < 0) return false;
+    return issued_before(NSTEPS - 1) == TOTAL;
+  }
   static constexpr int PATCH_FLOATS = NB * 256 * 4;
   static constexpr int CHUNK_FLOATS = PATCH_FLOATS + 9 * 1024;
   static constexpr size_t LDS = (size_t)CHUNKS * CHUNK_FLOATS * sizeof(float);
@@ -63,10 +78,40 @@ struct CsLane {
   int ppb, Wp;      // patch pixel under tap (0, 0) of this lane's output pixel; padded input width
 };
 
-// K-steps run in groups [0,1) [1,4) [4,9) [9,18): wait + barrier at the start of a group only (the DMA stream delivers a 4 KB weight
-// tile every ~0.1 us, a K-step computes for 0.43 us: after the first steps everything a group needs has long landed, and a barrier
-// + LDS round trip per K-step is a bubble the matrix pipe cannot hide with one wave per SIMD)
-__host__ __device__ constexpr int cs_group_end(int ks) { return ks == 0 ? 1 : ks == 1 ? 4 : ks == 4 ? 9 : ks == 9 ? 18 : 0; }
+// this thread's part of the DMA stream
+struct CsDma {
+  const float* in;     // patch origin, channel offset of the slice applied
+  const float* wgt;    // panel rows of this workgroup, first chunk of the slice
+  unsigned lds0, wvoff;
+  int tid, wid, PP, in_ld, cout;
+};
+template <class G, int D>
+__device__ __forceinline__ void cs_request(const CsDma& x) {
+  if constexpr (D < G::TOTAL) {
+    constexpr int c = D / G::PER_CHUNK, r = D % G::PER_CHUNK;
+    if constexpr (r < G::NB) {
+      // patch: slot = 16-byte column (slot & 7) of patch pixel (slot >> 3); slots past the patch re-read its last pixel
+      const int slot = r * 256 + x.tid;
+      const int p = min(slot >> 3, x.PP - 1);
+      const int col = (slot & 7) ^ ((p >> 1) & 7);
+      glds16<0>(x.in + c * 32, (unsigned)((p * x.in_ld + col * 4) * 4), x.lds0 + (unsigned)((c * G::CHUNK_FLOATS + (r * 256 + x.wid * 64) * 4) * 4));
+    } else {
+      // weight tile: row tid >> 3, column (tid & 7) ^ ((row >> 1) & 7)
+      constexpr int tap = r - G::NB;
+      glds16<0>(x.wgt + ((size_t)c * 9 + tap) * x.cout * 32, x.wvoff,
+                x.lds0 + (unsigned)((c * G::CHUNK_FLOATS + G::PATCH_FLOATS + tap * 1024 + x.wid * 256) * 4));
+    }
+  }
+}
+template <class G, int D0, int D1>
+struct CsRequestRange {      // requests D0 .. D1 - 1
+  static __device__ __forceinline__ void go(const CsDma& x) {
+    if constexpr (D0 < D1) {
+      cs_request<G, D0>(x);
+      CsRequestRange<G, D0 + 1, D1>::go(x);
+    }
+  }
+};
 
 struct CsFrag {
   float4 x[4], w[4];   // B (pixels) and A (weights) fragments of one K-step: four 8-channel groups
@@ -74,11 +119,8 @@ struct CsFrag {
 
 template <class G, int KS>
 __device__ __forceinline__ void cs_sync() {
-  if constexpr (cs_group_end(KS) > 0) {
-    constexpr int last = cs_group_end(KS) - 1, lc = last / 9, lt = last % 9;
-    cs_wait_vm<G::TOTAL - (lc * G::PER_CHUNK + G::NB + lt + 1)>();   // everything up to the group's last weight tile has landed
-    __syncthreads();
-  }
+  cs_wait_vm<G::outstanding(KS)>();     // everything up to this K-step's weight tile has landed (this wave's part) ...
+  __syncthreads();                      // ... and the other waves'
 }
 
 template <class G, int KS>
@@ -95,33 +137,34 @@ __device__ __forceinline__ void cs_load(const CsLane& f, CsFrag& fr) {
   }
 }
 
-__device__ __forceinline__ void cs_mma(const CsFrag& fr, f32x16& acc0, f32x16& acc1) {
-#pragma unroll
-  for (int g = 0; g < 4; g += 2) {
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].x, fr.x[g].x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].x, fr.x[g + 1].x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].y, fr.x[g].y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].y, fr.x[g + 1].y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].z, fr.x[g].z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].z, fr.x[g + 1].z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].w, fr.x[g].w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].w, fr.x[g + 1].w, acc1, 0, 0, 0);
-  }
+template <int G0>
+__device__ __forceinline__ void cs_mma(const CsFrag& fr, f32x16& acc0, f32x16& acc1) {   // groups G0, G0 + 1 of the K-step: 8 MFMAs
+  constexpr int g = G0;
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].x, fr.x[g].x, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].x, fr.x[g + 1].x, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].y, fr.x[g].y, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].y, fr.x[g + 1].y, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].z, fr.x[g].z, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].z, fr.x[g + 1].z, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g].w, fr.x[g].w, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.w[g + 1].w, fr.x[g + 1].w, acc1, 0, 0, 0);
 }
 
-// K-step KS: the fragments of KS + 1 are read (after its group's wait + barrier, if it starts one) BEFORE the 16 MFMAs of KS are
-// issued -- a K-step of matrix work (1,024 cycles) between an LDS read and its use.  sched_barrier pins that order: left to itself
-// the scheduler sinks the reads to one MFMA before their use (64 cycles, less than an LDS round trip: measured, EXPERIMENTS item 50)
+// K-step KS: wait + barrier for K-step KS + 1's weight tile, its fragments read, THEN the 16 MFMAs of KS with this K-step's DMA
+// requests in their middle -- a K-step of matrix work (1,024 cycles) between an LDS read and its use.  sched_barrier pins that
+// order: left to itself the scheduler sinks the reads to one MFMA before their use (64 cycles, less than an LDS round trip)
 template <class G, int KS>
 struct CsRun {
-  static __device__ __forceinline__ void go(const CsLane& f, CsFrag& fr0, CsFrag& fr1, f32x16& a0, f32x16& a1) {
-    CsRun<G, KS - 1>::go(f, fr0, fr1, a0, a1);
+  static __device__ __forceinline__ void go(const CsLane& f, const CsDma& x, CsFrag& fr0, CsFrag& fr1, f32x16& a0, f32x16& a1) {
+    CsRun<G, KS - 1>::go(f, x, fr0, fr1, a0, a1);
     if constexpr (KS + 1 < G::NSTEPS) {
       cs_sync<G, KS + 1>();
       cs_load<G, KS + 1>(f, (KS & 1) ? fr0 : fr1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    cs_mma((KS & 1) ? fr1 : fr0, a0, a1);
+    cs_mma<0>((KS & 1) ? fr1 : fr0, a0, a1);
+    CsRequestRange<G, G::issued_before(KS), G::issued_before(KS + 1)>::go(x);
+    cs_mma<2>((KS & 1) ? fr1 : fr0, a0, a1);
     __builtin_amdgcn_sched_barrier(0);
     if (KS == 3) { CS_TRACE(3) }
     if (KS == 8) { CS_TRACE(4) }
@@ -129,7 +172,7 @@ struct CsRun {
 };
 template <class G>
 struct CsRun<G, -1> {
-  static __device__ __forceinline__ void go(const CsLane& f, CsFrag& fr0, CsFrag&, f32x16&, f32x16&) {
+  static __device__ __forceinline__ void go(const CsLane& f, const CsDma&, CsFrag& fr0, CsFrag&, f32x16&, f32x16&) {
     cs_sync<G, 0>();
     CS_TRACE(2)
     cs_load<G, 0>(f, fr0);
@@ -163,24 +206,15 @@ __global__ __launch_bounds__(256, 1) void conv_slices_small_kernel(const ConvArg
   const float* __restrict__ wgt = a.w + (size_t)g * a.w_gs + ((size_t)sl * CHUNKS * 9 * cout + (size_t)nt * 32) * 32;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
 
-#pragma unroll
-  for (int c = 0; c < CHUNKS; ++c) {
-    // the patch: slot = 16-byte column (slot & 7) of patch pixel (slot >> 3); slots past the patch re-read its last pixel
-#pragma unroll
-    for (int j = 0; j < G::NB; ++j) {
-      const int slot = j * 256 + tid;
-      const int p = min(slot >> 3, PP - 1);
-      const int col = (slot & 7) ^ ((p >> 1) & 7);
-      glds16<0>(in + c * 32, (unsigned)((p * a.in_ld + col * 4) * 4), lds0 + (unsigned)((c * G::CHUNK_FLOATS + (j * 256 + wid * 64) * 4) * 4));
-    }
-    // the nine 32 x 32 weight tiles: row tid >> 3, column (tid & 7) ^ ((row >> 1) & 7)
+  static_assert(G::schedule_ok(), "a K-step would wait for a weight tile that has not been requested");
+  CsDma dma;
+  dma.in = in; dma.wgt = wgt; dma.lds0 = lds0;
+  dma.tid = tid; dma.wid = wid; dma.PP = PP; dma.in_ld = a.in_ld; dma.cout = cout;
+  {
     const int r0 = tid >> 3;
-    const unsigned wvoff = (unsigned)((r0 * 32 + (((tid & 7) ^ ((r0 >> 1) & 7)) << 2)) * 4);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-      glds16<0>(wgt + ((size_t)c * 9 + tap) * cout * 32, wvoff,
-                lds0 + (unsigned)((c * G::CHUNK_FLOATS + G::PATCH_FLOATS + tap * 1024 + wid * 256) * 4));
+    dma.wvoff = (unsigned)((r0 * 32 + (((tid & 7) ^ ((r0 >> 1) & 7)) << 2)) * 4);
   }
+  CsRequestRange<G, 0, G::AHEAD>::go(dma);
 
   CS_TRACE(1)
   CsLane f;
@@ -195,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void conv_slices_small_kernel(const ConvArg
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
   CsFrag fr0, fr1;
-  CsRun<G, CHUNKS * 9 - 1>::go(f, fr0, fr1, acc0, acc1);
+  CsRun<G, CHUNKS * 9 - 1>::go(f, dma, fr0, fr1, acc0, acc1);
 
 #if defined(SE3TN_SMALL_TRACE)
   if (acc0[0] + acc1[0] == 1.2345e-30f) return;   // (the accumulators are final before the stamp)

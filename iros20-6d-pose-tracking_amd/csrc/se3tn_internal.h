@@ -154,7 +154,7 @@ struct ConvArgs {
   // nullptr = separate conv_reduce_kernel launch.  epi / outf / resf: the epilogue the in-kernel reduction applies
   int* sem;
   int epi, outf, resf, rpt;   // rpt: reduce workgroups per output tile
-  int small_ok;               // the batch-1-2 kernels without a K split may be used (SE3TN_SMALL_KERNELS=0 switches them off)
+  int small_ok;               // the batch-1-5 kernel family (conv64_small, conv_slices_small) may be used (SE3TN_SMALL_KERNELS=0 switches them off)
   // f16x3 mode: per-cout power-of-two weight scale (acc * wscale = true sum), overflow flag,
   // fast = 0 (f32 everywhere) | 1 | 2 (see launch_conv3x3)
   const float* wscale;
@@ -264,7 +264,7 @@ hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* u
 #define SE3TN_STEM_SMALL_MAX_N 2
 #endif
 hipError_t launch_stem_pool_small(const float* inA, const float* inB, const float* w, const float* bias, float* pool, int n, hipStream_t st);
-// the 64 -> 64 trunk convs at batch 1-2 without a K split (conv64_small.hip)
+// the 64 -> 64 trunk convs at batch 1-5 without a K split (conv64_small.hip)
 hipError_t launch_conv64_small(const ConvArgs& a, int n, int epi, hipStream_t st);
 // the 128 .. 512-channel convs at batch 1-5: 128 pixels x 32 couts x one channel slice with all nine taps per workgroup
 // (conv_slices_small.hip); partial sums for conv_reduce_kernel
