@@ -6,10 +6,12 @@
 // 4 x 4 tile of POOL outputs of one branch: 121 tiles per image x 2 branches = 242 workgroups, one per CU.  It computes the 9 x 9
 // stem outputs under its pool windows (27 % more than its share: the one-pixel halo), applies bias + SELU, keeps them in LDS and
 // pools them from there: the 88 x 88 x 128 stem map is neither written nor read (4 MB each way per pair).
-//   * v_mfma_f32_16x16x4_f32: k = 4 is exactly ONE tap's four channels = one 16-byte input pixel.  A operand = weights (wave w =
-//     couts 16w..16w+15, the 49 taps' values of its lane live in registers for the whole kernel), B operand = pixels: one 4-byte
-//     LDS read per MFMA, at a compile-time offset from the lane's patch address (the 23 x 23 input patch is stored as it lies);
-//   * the packed stem weights are used as they are ([64][204]: slot e = tap (pair e / 2, half e % 2) of stem7x7_mfma.hip's pairing);
+//   * v_mfma_f32_16x16x4_f32 with k = FOUR TAPS of one channel: weight slots 4 g .. 4 g + 3 (13 groups cover the 49 taps; the three
+//     slots past the last tap carry zeros).  Lane (i, q) of the A operand holds cout i, slot 4 g + q: its four channels are ONE
+//     16-byte load from the packed row ([64][204]: slot e = tap (pair e / 2, half e % 2) of stem7x7_mfma.hip's pairing, used as it
+//     is); lane (j, q) of the B operand reads pixel j under THAT slot's tap: one 16-byte LDS read = the pixel's four channels.
+//     MFMA c of the group takes component c of both.  13 loads per lane for the weights and 13 LDS reads per 16-pixel block instead
+//     of 49 + 49 four-byte ones: the first version spent 3.5 of its 14 us issuing loads (scripts/small_trace.py, EXPERIMENTS item 53);
 //   * two pixel blocks in flight (independent accumulators), 6 blocks of 16 cover the 81 stem pixels;
 //   * edge tiles start their 9 x 9 window at stem row / column 0 instead of -1 (what lies outside the map is -inf for the pool: it
 //     is simply not looked at), so every patch lies inside the stored (zero-bordered) input.
@@ -19,6 +21,17 @@
 namespace se3tn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#if defined(SE3TN_SMALL_TRACE)   // developer build: phase stamps (100 MHz) of every workgroup, read back by scripts/small_trace.py
+static __device__ unsigned long long g_sp_trace[512][8];
+#define SP_TRACE(P)                                                                                      \
+  {                                                                                                      \
+    const unsigned lb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                 \
+    if (threadIdx.x == 0 && lb_ < 512) g_sp_trace[lb_][P] = wall_clock64();                              \
+  }
+#else
+#define SP_TRACE(P)
+#endif
 
 constexpr int SP_IP = RES + 6;          // 182: padded input rows / columns
 constexpr int SP_PW = 23;               // patch edge: 2 * 8 + 7
@@ -37,37 +50,64 @@ struct StemPoolArgs {
 __host__ __device__ constexpr int sp_tap_r(int e) { return e < 42 ? (e >> 1) / 3 : (e < 48 ? 2 * ((e >> 1) - 21) + (e & 1) : 6); }
 __host__ __device__ constexpr int sp_tap_s(int e) { return e < 42 ? 2 * ((e >> 1) % 3) + (e & 1) : 6; }
 
-// the 49 taps' B operands of two pixel blocks: one 4-byte LDS read each, at a compile-time offset from the lane's patch address.
-// ALL of a block pair's reads are issued before its first MFMA (and the next pair's while this one computes): issued next to their
-// use, each pair of MFMAs waited for an LDS round trip (EXPERIMENTS item 50: 14.2 us -> see there)
+constexpr int SP_GROUPS = 13;     // groups of four weight slots: 52 slots, 49 taps
+// float offset (inside the patch) of slot e's tap; slots 49 .. 51 do not exist: offset 0, their weights are forced to zero
+__host__ __device__ constexpr int sp_slot_off(int e) { return e < 49 ? (sp_tap_r(e) * SP_PW + sp_tap_s(e)) * 4 : 0; }
+
+// SELU with a short expm1: on (-0.5, 0] the Taylor series to v^9 (truncation < 3e-10 relative), below exp(v) - 1 through the
+// hardware exponential (the difference of 1 is at least 0.39 there: no cancellation).  ~17 vector instructions instead of the ~50
+// of expm1f -- vector work does not hide under this wave's own MFMAs (measured: the block pairs took MFMA time + SELU time), and
+// a lane computes 24 of these.  Within 2e-7 relative of expm1f; used by this kernel only.
+__device__ __forceinline__ float sp_selu(float v) {
+  const float t = v * (1.f / 9.f);
+  float p = fmaf(t, 1.f, 1.f);                       // 1 + v/9
+  p = fmaf(p * v, 1.f / 8.f, 1.f);
+  p = fmaf(p * v, 1.f / 7.f, 1.f);
+  p = fmaf(p * v, 1.f / 6.f, 1.f);
+  p = fmaf(p * v, 1.f / 5.f, 1.f);
+  p = fmaf(p * v, 1.f / 4.f, 1.f);
+  p = fmaf(p * v, 1.f / 3.f, 1.f);
+  p = fmaf(p * v, 1.f / 2.f, 1.f);
+  const float small = p * v;                         // v + v^2/2 + ... + v^9/9!
+  const float big = __expf(v) - 1.f;
+  const float em1 = v > -0.5f ? small : big;
+  return v > 0.f ? SELU_SCALE * v : (SELU_SCALE * SELU_ALPHA) * em1;
+}
+
+// B operands of two 16-pixel blocks: per group one 16-byte read each, at this lane's slot offset
 struct SpOperands {
-  float x0[49], x1[49];
+  float4 x0[SP_GROUPS], x1[SP_GROUPS];
 };
-__device__ __forceinline__ void sp_load(SpOperands& o, const float* p0, const float* p1) {
+__device__ __forceinline__ void sp_load(SpOperands& o, const float* p0, const float* p1, const int (&off)[SP_GROUPS]) {
 #pragma unroll
-  for (int e = 0; e < 49; ++e) {
-    const int off = (sp_tap_r(e) * SP_PW + sp_tap_s(e)) * 4;
-    o.x0[e] = p0[off];
-    o.x1[e] = p1[off];
+  for (int g = 0; g < SP_GROUPS; ++g) {
+    o.x0[g] = *reinterpret_cast<const float4*>(p0 + off[g]);
+    o.x1[g] = *reinterpret_cast<const float4*>(p1 + off[g]);
   }
 }
-// the MFMAs of one block pair, with the NEXT pair's operand reads interleaved one tap at a time and the PREVIOUS pair's bias + SELU
-// (eight expm1f per lane: ~0.9 us of vector work per pair) spread over the first eight taps -- vector instructions issue while
-// the matrix pipe works.  sched_barrier pins the order: left to itself the scheduler sinks every read to its use.
+// the MFMAs of one block pair (13 groups x 4 channels x 2 blocks), with the NEXT pair's operand reads interleaved one group at a
+// time and the PREVIOUS pair's bias + SELU spread over the first eight groups.  sched_barrier pins the order: left to itself the
+// scheduler sinks every read to its use.
 template <bool PREFETCH, bool EPI>
-__device__ __forceinline__ void sp_mma(const float (&w)[49], const SpOperands& o, SpOperands& nxt, const float* n0, const float* n1,
-                                       f32x4& a0, f32x4& a1, const f32x4& p0, const f32x4& p1, const float4& bias, float (&ov)[8]) {
+__device__ __forceinline__ void sp_mma(const float4 (&w)[SP_GROUPS], const SpOperands& o, SpOperands& nxt, const float* n0, const float* n1,
+                                       const int (&off)[SP_GROUPS], f32x4& a0, f32x4& a1, const f32x4& p0, const f32x4& p1,
+                                       const float4& bias, float (&ov)[8]) {
   const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll
-  for (int e = 0; e < 49; ++e) {
+  for (int g = 0; g < SP_GROUPS; ++g) {
     if (PREFETCH) {
-      const int off = (sp_tap_r(e) * SP_PW + sp_tap_s(e)) * 4;
-      nxt.x0[e] = n0[off];
-      nxt.x1[e] = n1[off];
+      nxt.x0[g] = *reinterpret_cast<const float4*>(n0 + off[g]);
+      nxt.x1[g] = *reinterpret_cast<const float4*>(n1 + off[g]);
     }
-    if (EPI && e < 8) ov[e] = selu_f((e < 4 ? p0[e & 3] : p1[e & 3]) + bv[e & 3]);
-    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], o.x0[e], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], o.x1[e], a1, 0, 0, 0);
+    if (EPI && g < 8) ov[g] = sp_selu((g < 4 ? p0[g & 3] : p1[g & 3]) + bv[g & 3]);
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g].x, o.x0[g].x, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g].x, o.x1[g].x, a1, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g].y, o.x0[g].y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g].y, o.x1[g].y, a1, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g].z, o.x0[g].z, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g].z, o.x1[g].z, a1, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g].w, o.x0[g].w, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g].w, o.x1[g].w, a1, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -76,6 +116,7 @@ __global__ __launch_bounds__(256) void stem_pool_small_kernel(const StemPoolArgs
   __shared__ __attribute__((aligned(16))) unsigned char smem[SP_PATCH_BYTES + 81 * 64 * 4];
   float* patch = reinterpret_cast<float*>(smem);
   float* stile = reinterpret_cast<float*>(smem + SP_PATCH_BYTES);     // [81 stem pixels][64 couts]
+  SP_TRACE(0)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x, img = blockIdx.y, br = blockIdx.z;
@@ -93,26 +134,34 @@ __global__ __launch_bounds__(256) void stem_pool_small_kernel(const StemPoolArgs
       glds16<0>(in, (unsigned)((py * SP_IP + px) * 16), lds0 + (unsigned)((j * 256 + wid * 64) * 16));
     }
   }
-  // ---- this lane's weights: cout 16 wid + (lane & 15), channel lane >> 4 of the 49 taps
-  float w[49];
+  // ---- this lane's weights: cout 16 wid + (lane & 15), slots 4 g + (lane >> 4): 13 loads of 16 bytes (the slots past tap 48 are zero)
+  const int kk = lane >> 4;
+  float4 w[SP_GROUPS];
   {
-    const float* wp = a.w + ((size_t)br * 64 + wid * 16 + (lane & 15)) * SP_WROW + (lane >> 4);
+    const float* wp = a.w + ((size_t)br * 64 + wid * 16 + (lane & 15)) * SP_WROW + kk * 4;
 #pragma unroll
-    for (int e = 0; e < 49; ++e) w[e] = wp[e * 4];
+    for (int g = 0; g < SP_GROUPS - 1; ++g) w[g] = *reinterpret_cast<const float4*>(wp + g * 16);
+    w[SP_GROUPS - 1] = kk == 0 ? *reinterpret_cast<const float4*>(wp + (SP_GROUPS - 1) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // ... and its slots' tap offsets inside the patch
+  int off[SP_GROUPS];
+#pragma unroll
+  for (int g = 0; g < SP_GROUPS; ++g)
+    off[g] = kk == 0 ? sp_slot_off(4 * g) : kk == 1 ? sp_slot_off(4 * g + 1) : kk == 2 ? sp_slot_off(4 * g + 2) : sp_slot_off(4 * g + 3);
   const int c = wid * 16 + (lane >> 4) * 4;              // the four couts this lane ends with
   const float4 bias = *reinterpret_cast<const float4*>(a.bias + br * 64 + c);
+  SP_TRACE(1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  SP_TRACE(2)
 
   // ---- 6 blocks of 16 stem pixels, two at a time; the operands of pair i + 1 are read while pair i computes
-  const int kk = lane >> 4;
   auto patch_ptr = [&](int blk) -> const float* {
     const int p = min(blk * 16 + (lane & 15), 80);
-    return patch + ((2 * (p / 9)) * SP_PW + 2 * (p % 9)) * 4 + kk;
+    return patch + ((2 * (p / 9)) * SP_PW + 2 * (p % 9)) * 4;
   };
   SpOperands ops[2];
-  sp_load(ops[0], patch_ptr(0), patch_ptr(1));
+  sp_load(ops[0], patch_ptr(0), patch_ptr(1), off);
   __builtin_amdgcn_sched_barrier(0);
   f32x4 acc[3][2];
   float ov[8];
@@ -127,20 +176,25 @@ __global__ __launch_bounds__(256) void stem_pool_small_kernel(const StemPoolArgs
 #pragma unroll
     for (int e = 0; e < 4; ++e) { acc[it][0][e] = 0.f; acc[it][1][e] = 0.f; }
     if (it == 0)
-      sp_mma<true, false>(w, ops[0], ops[1], patch_ptr(2), patch_ptr(3), acc[0][0], acc[0][1], acc[0][0], acc[0][1], bias, ov);
+      sp_mma<true, false>(w, ops[0], ops[1], patch_ptr(2), patch_ptr(3), off, acc[0][0], acc[0][1], acc[0][0], acc[0][1], bias, ov);
     else if (it == 1)
-      sp_mma<true, true>(w, ops[1], ops[0], patch_ptr(pb + 2), patch_ptr(pb + 3), acc[1][0], acc[1][1], acc[0][0], acc[0][1], bias, ov);
+      sp_mma<true, true>(w, ops[1], ops[0], patch_ptr(pb + 2), patch_ptr(pb + 3), off, acc[1][0], acc[1][1], acc[0][0], acc[0][1], bias, ov);
     else
-      sp_mma<false, true>(w, ops[0], ops[0], nullptr, nullptr, acc[2][0], acc[2][1], acc[1][0], acc[1][1], bias, ov);
+      sp_mma<false, true>(w, ops[0], ops[0], nullptr, nullptr, off, acc[2][0], acc[2][1], acc[1][0], acc[1][1], bias, ov);
     if (it > 0) store_pair(it - 1);
+#if defined(SE3TN_SMALL_TRACE)
+    if (acc[it][0][0] == 1.2345e-30f) return;
+    if (it == 0) { SP_TRACE(3) } else if (it == 1) { SP_TRACE(4) } else { SP_TRACE(5) }
+#endif
   }
   {
     const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ov[e] = selu_f((e < 4 ? acc[2][0][e & 3] : acc[2][1][e & 3]) + bv[e & 3]);
+    for (int e = 0; e < 8; ++e) ov[e] = sp_selu((e < 4 ? acc[2][0][e & 3] : acc[2][1][e & 3]) + bv[e & 3]);
     store_pair(2);
   }
   __syncthreads();
+  SP_TRACE(6)
 
   // ---- MaxPool2d(3, 2, 1) of the tile: thread = (pool pixel, 4 couts); rows / columns outside the 88 x 88 map do not exist
   {
@@ -161,7 +215,17 @@ __global__ __launch_bounds__(256) void stem_pool_small_kernel(const StemPoolArgs
     }
     *reinterpret_cast<float4*>(a.pool + (((size_t)img * (S2 + 2) + i + 1) * (S2 + 2) + j + 1) * 128 + br * 64 + c4) = m;
   }
+#if defined(SE3TN_SMALL_TRACE)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SP_TRACE(7)
+#endif
 }
+
+#if defined(SE3TN_SMALL_TRACE)
+extern "C" int se3tn_debug_trace_stem(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sp_trace), sizeof(unsigned long long) * 512 * 8);
+}
+#endif
 
 hipError_t launch_stem_pool_small(const float* inA, const float* inB, const float* w, const float* bias, float* pool, int n,
                                   hipStream_t st) {

@@ -22,3 +22,14 @@ for i, nme in enumerate(names):
     print("  %-14s %6.2f [%6.2f .. %6.2f]" % (nme, rel[:, i].mean(), rel[:, i].min(), rel[:, i].max()))
 d = np.diff(rel, axis=1)
 print("  per workgroup: " + " | ".join("%s %.2f" % (n, v) for n, v in zip(["issue", "wait first", "steps 0-3", "steps 4-8", "steps 9-17", "store"], d.mean(0))))
+
+if hasattr(lib, "se3tn_debug_trace_stem"):
+    b2 = np.zeros((512, 8), np.uint64)
+    lib.se3tn_debug_trace_stem.argtypes = [C.c_void_p]
+    assert lib.se3tn_debug_trace_stem(b2.ctypes.data) == 0
+    t = b2[:242].astype(np.int64)
+    rel = (t - t[:, 0].min()) / 100.0
+    names = ["entry", "loads issued", "data landed", "block pair 0", "block pair 1", "block pair 2", "SELU + LDS done", "pooled + stored"]
+    print("stem_pool_small_kernel, us after the first workgroup's entry: mean [min .. max] over 242 workgroups")
+    for i, nme in enumerate(names):
+        print("  %-16s %6.2f [%6.2f .. %6.2f]" % (nme, rel[:, i].mean(), rel[:, i].min(), rel[:, i].max()))
