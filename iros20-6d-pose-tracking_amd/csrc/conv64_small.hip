@@ -44,7 +44,7 @@ struct C64Frag {
 // DMA schedule: the patch and the first C64_AHEAD weight tiles are requested before the first K-step; K-step ks requests tile
 // ks + C64_AHEAD between its MFMAs (the issue of an LDS-DMA instruction blocks the wave for ~35 cycles while the four waves share the
 // address pipe: 153 KB issued up front kept the matrix pipe idle for 1.9 us of a 4 us kernel -- scripts/small_trace.py, EXPERIMENTS
-// item 50).  c64_outstanding(s) = DMA instructions issued AFTER tile s's two at the moment K-step s synchronises (in the body of
+// item 51).  c64_outstanding(s) = DMA instructions issued AFTER tile s's two at the moment K-step s synchronises (in the body of
 // K-step s - 1, before that body's own request): what `s_waitcnt vmcnt` may leave in flight.
 constexpr int C64_AHEAD = 4;
 __host__ __device__ constexpr int c64_tiles_issued(int s) { return s == 0 ? C64_AHEAD : (s + C64_AHEAD - 1 < C64_KSTEPS ? s + C64_AHEAD - 1 : C64_KSTEPS); }

@@ -56,7 +56,7 @@ struct CsGeom {
   // DMA schedule (instruction index d: chunk d / PER_CHUNK; inside a chunk NB patch instructions, then the nine weight tiles):
   // AHEAD = the first chunk's patch + its first four tiles are requested before the first K-step, every K-step requests RATE more
   // from between its MFMAs.  (Issuing an LDS-DMA instruction blocks the wave ~35 cycles while the four waves share the address
-  // pipe: with all 30 up front the matrix pipe idled for the first 1.9 us -- scripts/small_trace.py, EXPERIMENTS item 50.)
+  // pipe: with all 30 up front the matrix pipe idled for the first 1.9 us -- scripts/small_trace.py, EXPERIMENTS item 51.)
   static constexpr int AHEAD = NB + 4, RATE = 2;
   static constexpr int issued_before(int ks) { return AHEAD + RATE * ks < TOTAL ? AHEAD + RATE * ks : TOTAL; }   // ... K-step ks's own requests
   static constexpr int tile_index(int ks) { return (ks / 9) * PER_CHUNK + NB + ks % 9; }
@@ -182,8 +182,8 @@ struct CsRun<G, -1> {
 // grid: (slices x n-tiles, m-tiles x images, groups) workgroups of 256 threads; the slice is the fastest index: consecutive
 // workgroups go to consecutive XCDs, so the workgroups that read the same input channels share an L2.  Everything about the
 // layer's geometry is a template constant: the index arithmetic of a kernel whose whole life is 12 us must not contain a division by
-// a run-time value (the first version spent 2.6 us between entry and its last DMA issue: EXPERIMENTS item 50).
-// The partial sums go to conv_reduce_kernel (next launch).  Measured alternative (EXPERIMENTS item 50): the reduction in THIS launch
+// a run-time value (the first version spent 2.6 us between entry and its last DMA issue: EXPERIMENTS item 51).
+// The partial sums go to conv_reduce_kernel (next launch).  Measured alternative (EXPERIMENTS item 51): the reduction in THIS launch
 // -- partial tiles written through to memory with sc1 stores, a ticket per output tile, the last arriver reads the SLICES tiles back
 // with sc1 loads, adds them in slice order and applies the epilogue: 210 us per forward against 183 us with the separate launch.
 // Three dependent round trips to the memory side (store acknowledgements, ticket, read-back) cost more than a launch boundary.
