@@ -48,7 +48,7 @@ def test_small_batch_family_vs_oracle_and_general_kernels(se3, n):
     names = [nm for nm, _ in eng.profile_launches(0)]
     eng.profile_enable(0)
     assert any("small tiles" in nm for nm in names) == (n <= 2), names          # stem + pool in one launch at 1-2 pairs
-    assert not any("maxpool" in nm for nm in names) == (n <= 2)
+    assert ("maxpool3x3s2" in names) == (n > 2), names                          # ... the batch-64 pair of kernels from 3 pairs
     eng.set_small_kernels(False)
     general = _logits(m, Ac, Bc, n)
     eng.set_small_kernels(True)
