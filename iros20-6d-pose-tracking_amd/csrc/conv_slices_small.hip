@@ -1,5 +1,5 @@
 // The 128 .. 512-channel 3x3 convs (convAB1, convAB2, trans|rot conv1 / conv2: se3_tracknet.py:74-97, network_modules.py:86-120) at
-// batch 1-5: the regime Tracker.on_track runs in.  At one pair they are 136 of the forward's 230 us (EXPERIMENTS item 45), and what
+// batch 1-5: the regime Tracker.on_track runs in.  At one pair they were 136 of the forward's 230 us (EXPERIMENTS items 45, 50), and what
 // bounds them is not bytes but the float32 matrix rate: 2.6 GFLOP / 157 TFLOP/s = 17 us on 256 compute units -- if every one of them
 // computes.  conv3x3_splitk_kernel's 128 x 128 tiles leave 8-32 output tiles per layer, so it cuts K into 12-48 runs of THREE K-steps:
 // each workgroup starts, waits for its first bytes, computes for a microsecond and stores a 64 KB partial tile (24 MB of partial sums
