@@ -32,11 +32,14 @@ namespace se3tn {
 // -DSE3TN_SMALL_TRACE (developer build, scripts/small_trace.py): thread 0 of every workgroup stamps wall_clock64() (100 MHz) at the
 // kernel's phase boundaries; the last launch's stamps are read back with se3tn_debug_trace_slices()
 #if defined(SE3TN_SMALL_TRACE)
-static __device__ unsigned long long g_cs_trace[1024][8];
+static __device__ unsigned long long g_cs_trace[2][1024][8];   // [0]: wall_clock64() (100 MHz), [1]: clock64() (s_memtime: core clock)
 #define CS_TRACE(P)                                                                                      \
   {                                                                                                      \
     const unsigned lb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                 \
-    if (threadIdx.x == 0 && lb_ < 1024) g_cs_trace[lb_][P] = wall_clock64();                             \
+    if (threadIdx.x == 0 && lb_ < 1024) {                                                                \
+      g_cs_trace[0][lb_][P] = wall_clock64();                                                            \
+      g_cs_trace[1][lb_][P] = clock64();                                                                 \
+    }                                                                                                    \
   }
 #else
 #define CS_TRACE(P)
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void conv_slices_small_kernel(const ConvArg
 
 #if defined(SE3TN_SMALL_TRACE)
 extern "C" int se3tn_debug_trace_slices(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_trace), sizeof(unsigned long long) * 1024 * 8);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_trace), sizeof(unsigned long long) * 2 * 1024 * 8);
 }
 #endif
 

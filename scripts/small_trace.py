@@ -10,9 +10,14 @@ A, B = Fx.net_inputs(1, 1); Ac, Bc = A.cuda(), B.cuda()
 for _ in range(20): m(Ac, Bc, return_feature=False)
 torch.cuda.synchronize()
 lib = m.engine.lib
-buf = np.zeros((1024, 8), np.uint64)
+buf2 = np.zeros((2, 1024, 8), np.uint64)
 lib.se3tn_debug_trace_slices.argtypes = [C.c_void_p]
-assert lib.se3tn_debug_trace_slices(buf.ctypes.data) == 0
+assert lib.se3tn_debug_trace_slices(buf2.ctypes.data) == 0
+buf = buf2[0]
+cyc = buf2[1][:256, :7].astype(np.int64)
+wal = buf2[0][:256, :7].astype(np.int64)
+ratio = (cyc[:, 5] - cyc[:, 2]) / np.maximum(wal[:, 5] - wal[:, 2], 1) * 100.0     # clock64 ticks per microsecond over the K-step phase
+print("clock64() ticks per us of wall_clock64() over the K-step phase: mean %.1f [%.1f .. %.1f]  (100 = a constant 100 MHz counter; ~2400 = the core clock)" % (ratio.mean(), ratio.min(), ratio.max()))
 t = buf[:256, :7].astype(np.int64)            # the last conv_slices launch: trans|rot conv2.conv2 (256 workgroups)
 t0 = t[:, 0].min()
 rel = (t - t0) / 100.0
