@@ -143,8 +143,8 @@ class Engine:
         return "numpy2" if self.lib.se3tn_get_offset_rule(self._h) == _lib.OFFSET_RULE_NUMPY2 else "numpy1"
 
     def set_small_kernels(self, on=True):
-        """Batches of 1-2 pairs through the small-tile stem + pool / trunk kernels (default) or through the general kernels (False):
-        include/se3tracknet.h, se3tn_set_small_kernels."""
+        """Batches of 1-5 pairs through the batch-1 kernel family (conv64_small, conv_slices_small; the small-tile stem + pool at 1-2
+        pairs) -- the default -- or through the general kernels (False): include/se3tracknet.h, se3tn_set_small_kernels."""
         check(self.lib.se3tn_set_small_kernels(self._h, 1 if on else 0), "se3tn_set_small_kernels")
 
     def get_small_kernels(self):

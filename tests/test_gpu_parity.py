@@ -224,7 +224,7 @@ def test_fused_trunk_winograd_vs_direct_and_oracle(se3, golden_dir):
     _close("trans vs golden", ow["trans"].cpu(), torch.from_numpy(g["trans"]), 0, NET_TOL)
     _close("rot vs golden", ow["rot"].cpu(), torch.from_numpy(g["rot"]), 0, NET_TOL)
     # every pair of a forced batch of 5 equals that pair alone through the same kernel (a workgroup never spans two images): bitwise.
-    # (The batch-1-2 stem / trunk kernels are another algorithm -- switched off here so that one pair runs the same kernels as five.)
+    # (At 1-2 pairs the stem + pool take another kernel than at five -- switched off here so that one pair runs the same kernels as five.)
     eng.set_small_kernels(False)
     A5, B5 = Fx.net_inputs(9, 5)
     m(A5.cuda(), B5.cuda(), return_feature=False)
