@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Free-running two-track comparison (oracle/free_run.py) as a stand-alone report: HIP tracker's own closed loop vs the
+oracle's own closed loop, + the oracle-vs-itself control.   python scripts/free_run_report.py [frames] [seeds] > report.json"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+if __name__ == "__main__":
+    import se3tracknet_amd as se3
+    from oracle import free_run
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    seeds = tuple(range(int(sys.argv[2]))) if len(sys.argv) > 2 else (0, 1, 2)
+    r = free_run.run_free(se3, frames=frames, seeds=seeds, control_seeds=seeds)
+    print(json.dumps(r))
