@@ -878,6 +878,9 @@ def cpu_quota_cores():
     return None
 
 
+CPU_SAMPLES = 3                      # samples per cpu_baseline configuration (median + spread are reported)
+
+
 def _cpu_worker(cpus, threads, seconds, chunk, start, q):
     """One pinned oracle process of the cpu_baseline: the WHOLE per-pair path (crop_bbox + processData on numpy, the network
     on torch-CPU in forwards of `chunk` pairs, processPredict), for `seconds` after a common start."""
@@ -907,17 +910,20 @@ def _cpu_worker(cpus, threads, seconds, chunk, start, q):
         q.put(("ready", 0))
         if not start.wait(timeout=300):
             return
-        t0 = time.perf_counter(); n = 0
-        while time.perf_counter() - t0 < seconds:
-            one_chunk(); n += chunk
-        q.put((n, time.perf_counter() - t0))
+        wins = []
+        for _ in range(CPU_SAMPLES):                     # consecutive windows of seconds / CPU_SAMPLES: one sample each
+            t0 = time.perf_counter(); n = 0
+            while time.perf_counter() - t0 < seconds / CPU_SAMPLES:
+                one_chunk(); n += chunk
+            wins.append((n, time.perf_counter() - t0))
+        q.put(("done", wins))
     except Exception as e:   # noqa: BLE001
         q.put(("error", repr(e)))
 
 
 def cpu_multiprocess_rate(procs, threads, seconds, chunk, cores):
     """`procs` pinned oracle processes x `threads` threads, disjoint blocks of physical cores, common start (barrier);
-    returns whole-path pairs/s = all pairs finished / the slowest worker's time."""
+    returns CPU_SAMPLES whole-path rates [pairs/s], one per window = all pairs finished in it / the slowest worker's time."""
     import multiprocessing as mp
     import queue as queue_mod
     ctx = mp.get_context("spawn")
@@ -950,13 +956,58 @@ def cpu_multiprocess_rate(procs, threads, seconds, chunk, cores):
         w.join(timeout=30)
     if err is not None:
         return None, err
-    return sum(r[0] for r in res) / max(r[1] for r in res), None
+    wins = [r[1] for r in res]
+    return [sum(w[i][0] for w in wins) / max(w[i][1] for w in wins) for i in range(CPU_SAMPLES)], None
+
+
+def _median_spread(samples):
+    """median of the samples and (max - min) / median"""
+    import numpy as np
+    med = float(np.median(samples))
+    return round(med, 2), [round(float(v), 2) for v in samples], round((max(samples) - min(samples)) / med, 4) if med > 0 else None
+
+
+def reference_vs_port(O, sd, threads):
+    """The UNMODIFIED reference Se3TrackNet on torch-CPU next to the oracle port, same weights / inputs / threads (forwards of 16 and
+    of 1): only where the reference tree exists (the build container; never the GPU box)."""
+    if not os.path.isdir("/root/reference"):
+        return {"value": None, "reason": "/root/reference does not exist on this box (it never travels to the GPU box); measured on the "
+                                         "build container: profiles/r05_cpu_reference_vs_port.txt (port / reference time 0.89 / 1.02 / 1.20 at "
+                                         "batch 1 / 16 / 64, outputs bit-identical)"}
+    try:
+        import numpy as np
+        import torch
+        from oracle import fixtures as Fx, ref_shims
+        from oracle.make_golden import ref_model
+        model = ref_model(ref_shims.load(), sd)
+        torch.set_num_threads(threads)
+        out = {"threads": threads}
+        for n in (1, 16):
+            A, B = Fx.net_inputs(3, n)
+
+            def med(fn, reps=5):
+                fn(); ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+                return float(np.median(ts))
+            with torch.no_grad():
+                tr = med(lambda: model(A, B))
+                r = model(A, B)
+            tp = med(lambda: O.forward(sd, A, B))
+            o = O.forward(sd, A, B)
+            out["batch_%d" % n] = {"reference_pairs_per_s": round(n / tr, 2), "port_pairs_per_s": round(n / tp, 2),
+                                   "port_over_reference_time": round(tp / tr, 3),
+                                   "max_abs_output_diff": max(float((r["trans"] - o["trans"]).abs().max()), float((r["rot"] - o["rot"]).abs().max()))}
+        return out
+    except Exception as e:   # noqa: BLE001   (the baseline must not take the bench line down)
+        return {"value": None, "reason": "reference import failed: %r" % (e,)}
 
 
 def cpu_baseline(O, sd, nb, inputs=None):
     """The CPU oracle (torch-CPU fp32 restatement of the reference network + numpy pre/post) timed on this box's host cores
-    on a bounded sample (~40 s).  `value` = the BEST whole-path configuration measured in THIS run (every configuration is
-    timed once, for the same duration, and the reported figure is that measurement -- never a sweep winner re-timed).
+    on a bounded sample (~30 s).  `value` = the MEDIAN of CPU_SAMPLES samples of the best whole-path configuration measured in THIS
+    run (every configuration is timed for the same duration, split into CPU_SAMPLES consecutive windows; `samples` / `spread`
+    = (max - min) / median beside it -- the host is shared, one window is thin).
     The usable cores are min(physical cores, the container's cgroup CPU quota): configurations are one process with Q and Q/2
     threads, K pinned processes x T threads with K T = Q on disjoint physical cores, and ONE over-quota configuration (2 Q
     threads) that documents the throttling.  Batch 1 (what the reference's live tracker runs) beside it."""
@@ -970,7 +1021,7 @@ def cpu_baseline(O, sd, nb, inputs=None):
     quota = cpu_quota_cores()
     Q = max(1, min(P, int(quota) if quota else P))   # cores this container can keep busy
     A, B = inputs if inputs is not None else Fx.net_inputs(3, nb)
-    SECONDS, CHUNK = 4.0, 16
+    SECONDS, CHUNK = 4.5, 16
     mean, std = Fx.mean_std(0)
     rgb, depth = Fx.synthetic_frame(3); Pz = Fx.pose(3); rgbA, depthA = Fx.synthetic_render(103, 0.8)
     t0 = time.perf_counter()
@@ -990,15 +1041,18 @@ def cpu_baseline(O, sd, nb, inputs=None):
             pass
         torch.set_num_threads(th)
         O.forward(sd, A[:CHUNK], B[:CHUNK])
-        t0 = time.perf_counter(); n = 0; c0 = 0
-        while time.perf_counter() - t0 < SECONDS:
-            O.forward(sd, A[c0:c0 + CHUNK], B[c0:c0 + CHUNK]); n += min(CHUNK, nb - c0)
-            c0 = (c0 + CHUNK) % max(CHUNK, nb - nb % CHUNK)
-        net = n / (time.perf_counter() - t0)
-        configs["1 x %d" % th] = {"processes": 1, "threads": th, "value": round(1.0 / (1.0 / net + pp_s_per_pair), 2),
-                                  "network_only": round(net, 2)}
+        nets, c0 = [], 0
+        for _ in range(CPU_SAMPLES):
+            t0 = time.perf_counter(); n = 0
+            while time.perf_counter() - t0 < SECONDS / CPU_SAMPLES:
+                O.forward(sd, A[c0:c0 + CHUNK], B[c0:c0 + CHUNK]); n += min(CHUNK, nb - c0)
+                c0 = (c0 + CHUNK) % max(CHUNK, nb - nb % CHUNK)
+            nets.append(n / (time.perf_counter() - t0))
+        med, smp, spread = _median_spread([1.0 / (1.0 / net + pp_s_per_pair) for net in nets])
+        configs["1 x %d" % th] = {"processes": 1, "threads": th, "value": med, "samples": smp, "spread": spread,
+                                  "network_only": round(float(np.median(nets)), 2)}
     # batch 1: best of a small thread sweep, 10 forwards each
-    b1 = {}
+    b1, b1_samples = {}, {}
     for th in sorted({t for t in (max(1, Q // 2), Q) if t <= P} or {P}):
         try:
             os.sched_setaffinity(0, set(cores[:th]))
@@ -1006,10 +1060,14 @@ def cpu_baseline(O, sd, nb, inputs=None):
             pass
         torch.set_num_threads(th)
         O.forward(sd, A[:1], B[:1])
-        t0 = time.perf_counter()
-        for _ in range(10):
-            O.forward(sd, A[:1], B[:1])
-        b1[th] = round(10.0 / (time.perf_counter() - t0), 2)
+        smp = []
+        for _ in range(CPU_SAMPLES):
+            t0 = time.perf_counter()
+            for _ in range(8):
+                O.forward(sd, A[:1], B[:1])
+            smp.append(8.0 / (time.perf_counter() - t0))
+        b1[th] = round(float(np.median(smp)), 2)
+        b1_samples[th] = [round(v, 2) for v in smp]
     try:
         os.sched_setaffinity(0, old_aff)
     except OSError:
@@ -1020,27 +1078,31 @@ def cpu_baseline(O, sd, nb, inputs=None):
         th = Q // k
         if th < 2:
             continue
-        rate, err = cpu_multiprocess_rate(k, th, SECONDS, CHUNK, cores)
-        if rate is None:
+        rates, err = cpu_multiprocess_rate(k, th, SECONDS, CHUNK, cores)
+        if rates is None:
             errors["%d x %d" % (k, th)] = err
             continue
-        configs["%d x %d" % (k, th)] = {"processes": k, "threads": th, "value": round(rate, 2)}
+        med, smp, spread = _median_spread(rates)
+        configs["%d x %d" % (k, th)] = {"processes": k, "threads": th, "value": med, "samples": smp, "spread": spread}
     best = max(configs, key=lambda k_: configs[k_]["value"])
     single = max((k_ for k_ in configs if configs[k_]["processes"] == 1), key=lambda k_: configs[k_]["value"])
     b1_best = max(b1, key=b1.get)
     torch.set_num_threads(min(32, P))
     out = {"value": configs[best]["value"], "unit": "pairs/s", "cores": configs[best]["processes"] * configs[best]["threads"],
+           "samples": configs[best]["samples"], "spread": configs[best]["spread"],
            "kind": "port", "configuration": best + " (processes x threads, pinned to disjoint physical cores)",
            "cpu_model": model, "sockets": sockets, "logical_cpus": ncpu, "physical_cores": P,
            "cgroup_cpu_quota_cores": quota, "usable_cores": Q,
            "configurations_pairs_per_s": configs,
            "single_process_best": {"configuration": single, "value": configs[single]["value"], "cores": configs[single]["threads"]},
            "batch1": {"value": round(1.0 / (1.0 / b1[b1_best] + pp_s_per_pair), 2), "cores": b1_best,
-                      "network_only_by_threads": b1, "unit": "pairs/s"},
+                      "network_only_by_threads": b1, "network_only_samples_by_threads": b1_samples, "unit": "pairs/s"},
            "prepost_ms_per_pair": round(pp_s_per_pair * 1e3, 3),
            "sample": "oracle (torch-CPU fp32 port of the reference network + numpy crop / normalise / pose update; %s x%d sockets, "
-                     "%d physical cores, cgroup CPU quota %s cores): every configuration timed once for %.0f s in forwards of %d pairs; "
-                     "value = the best of them" % (model, sockets, P, ("%.0f" % quota) if quota else "none", SECONDS, CHUNK)}
+                     "%d physical cores, cgroup CPU quota %s cores): every configuration timed for %.1f s = %d consecutive samples, in forwards of %d "
+                     "pairs; value = the median of the best configuration's samples, spread = (max - min) / median"
+                     % (model, sockets, P, ("%.0f" % quota) if quota else "none", SECONDS, CPU_SAMPLES, CHUNK)}
+    out["reference_vs_port"] = reference_vs_port(O, sd, Q)
     if errors:
         out["configurations_failed"] = errors
     return out

@@ -231,7 +231,9 @@ int se3tn_get_small_kernels(const se3tn_ctx* ctx);
  * goldens were rendered on (tests/golden/gl_swiftshader*.npz), reproduced byte for byte: window coordinates snapped to
  * 1 / 2^sub_bits pixel (4 = that implementation = the GL minimum GL_SUBPIXEL_BITS, default; 8 = what desktop GPUs report),
  * integer top-left coverage, that implementation's plane-equation arithmetic and 16-bit unorm conversion.  The depth read-back
- * (vispy_renderer.py:163-169) mixes a float32 array with float64 scalars: it follows se3tn_set_offset_rule's NumPy generation. */
+ * (vispy_renderer.py:163-169) mixes a float32 array with float64 scalars: it follows se3tn_set_offset_rule's NumPy generation.
+ * sub_bits = 8 has NO golden: no desktop GL is reachable from the build / test boxes, so that setting is the same arithmetic
+ * with a finer snap and is pinned by nothing but the rule tests (oracle/pin_gl.py pins it on first contact with such a GL). */
 int se3tn_set_raster_rule(se3tn_ctx* ctx, int sub_bits);
 int se3tn_get_raster_rule(const se3tn_ctx* ctx);
 

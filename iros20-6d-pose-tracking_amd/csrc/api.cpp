@@ -36,6 +36,8 @@ enum { MAX_LAUNCHES = 24, MAX_SLOTS = 64 };
 struct GraphKey {
   const void *A, *B, *trans, *rot, *poseA, *poseB, *blob;
   int n, layout, prec, wino_min_batch, wino_tile, keep, wino64, wino64_fill;
+  int small_kernels, splitk_fused, wino_fuse, gemmp;   // every switch that selects a kernel family (a graph captured under another
+                                                       // setting must not be replayed)
   double tn, rn;
   bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
 };
@@ -104,6 +106,7 @@ struct se3tn_ctx {
   // se3tn_on_track: pinned host staging [pose 128 B | frame window rgb | depth], its device mirror, device outputs and their pinned copy
   uint8_t* trk_host = nullptr; uint8_t* trk_dev = nullptr; size_t trk_bytes = 0;
   uint8_t* trk_out_dev = nullptr; uint8_t* trk_out_host = nullptr;   // ONE mapped pinned block: device address | host address
+  bool rearm_counters = false;                  // a failed launch sequence: clear tail_arrive / splitk_sem before the next one
   int* tail_arrive = nullptr;                   // [max_batch] arrival counters of tail_kernel's 16 workgroups per pair (zero between launches)
   int* tail_flag = nullptr; int tail_seq = 0;   // set around se3tn_on_track's infer: the tail kernel stores tail_seq to this (mapped) word
   hipStream_t trk_copy_stream = nullptr; hipEvent_t trk_copy_event = nullptr;
@@ -668,8 +671,25 @@ int se3tn_enable_graphs(se3tn_ctx* c, int on) {
 // With graphs enabled, the ~25 dependent launches of one se3tn_infer are captured once per argument
 // set (second call with identical arguments; the first runs eagerly) and replayed with one
 // hipGraphLaunch afterwards: the batch-1 tracking step is launch-bound (kernels of 10-30 us).
+static int infer_graph_or_launch(se3tn_ctx* c, const float* A, const float* B, int n, int layout, float* trans, float* rot,
+                                 const double* poseA, double* poseB, void* stream);
+
 int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout, float* trans, float* rot,
                 const double* poseA, double* poseB, void* stream) {
+  if (c && c->rearm_counters && c->device >= 0 && !stream_is_capturing((hipStream_t)stream)) {
+    // a launch sequence that failed half-way can leave the tail's arrival counters / the split-K semaphores non-zero, and every
+    // later frame would then find no "last" workgroup: clear them, stream-ordered, before the next frame
+    if (c->tail_arrive) HIPCHK(hipMemsetAsync(c->tail_arrive, 0, sizeof(int) * c->max_batch, (hipStream_t)stream));
+    if (c->splitk_sem) HIPCHK(hipMemsetAsync(c->splitk_sem, 0, sizeof(int) * 2 * SE3TN_SPLITK_MAX_TILES, (hipStream_t)stream));
+    c->rearm_counters = false;
+  }
+  const int rc = infer_graph_or_launch(c, A, B, n, layout, trans, rot, poseA, poseB, stream);
+  if (rc != SE3TN_OK && rc != SE3TN_E_ARG && rc != SE3TN_E_STATE && c) c->rearm_counters = true;
+  return rc;
+}
+
+static int infer_graph_or_launch(se3tn_ctx* c, const float* A, const float* B, int n, int layout, float* trans, float* rot,
+                                 const double* poseA, double* poseB, void* stream) {
   if (!c || !c->use_graphs || c->prof || stream == nullptr)  // the null stream cannot be captured
     return infer_launch(c, A, B, n, layout, trans, rot, poseA, poseB, stream);
   GraphKey key;
@@ -678,6 +698,8 @@ int se3tn_infer(se3tn_ctx* c, const float* A, const float* B, int n, int layout,
   key.n = n; key.layout = layout; key.prec = c->prec;
   key.wino_min_batch = c->wino_min_batch; key.wino_tile = c->wino_tile; key.keep = c->keep_intermediates ? 1 : 0;
   key.wino64 = c->wino64_min_batch; key.wino64_fill = c->wino64_min_fill; key.tn = c->tn; key.rn = c->rn;
+  key.small_kernels = c->small_kernels ? 1 : 0; key.splitk_fused = c->splitk_fused ? 1 : 0; key.wino_fuse = c->wino_fuse ? 1 : 0;
+  key.gemmp = c->gemmp;
   hipStream_t st = (hipStream_t)stream;
   for (auto& g : c->graphs) {
     if (!(g.key == key)) continue;
@@ -1088,19 +1110,23 @@ int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const 
 static double round_half_even(double x) { return std::nearbyint(x); }
 
 // Utils.py:302-316 compute_bbox with scale (1000, sy, 1000) -> (left, top, right, bottom) = min / max of the (u, v) corners
-static void bbox_window(const double pose[16], const double K[9], double width, double sy, int32_t win[4], int32_t vu[8]) {
+// Returns false when a corner is not a finite value inside the int32 range (z == 0, NaN, a pose at the camera centre): the
+// float -> int cast would be undefined behaviour.
+static bool bbox_window(const double pose[16], const double K[9], double width, double sy, int32_t win[4], int32_t vu[8]) {
   const double x = pose[3] * 1000, y = pose[7] * sy, z = pose[11] * 1000, off = width / 2;
   const double px[4] = {x - off, x - off, x + off, x + off};
   const double py[4] = {y - off, y + off, y - off, y + off};
   int32_t umin = INT32_MAX, umax = INT32_MIN, vmin = INT32_MAX, vmax = INT32_MIN;
   for (int i = 0; i < 4; ++i) {
-    const int32_t u = (int32_t)round_half_even(px[i] * K[0] / z + K[2]);
-    const int32_t v = (int32_t)round_half_even(py[i] * K[4] / z + K[5]);
+    const double uf = round_half_even(px[i] * K[0] / z + K[2]), vf = round_half_even(py[i] * K[4] / z + K[5]);
+    if (!(std::fabs(uf) < 1.0e9) || !(std::fabs(vf) < 1.0e9)) return false;   // (also false for NaN)
+    const int32_t u = (int32_t)uf, v = (int32_t)vf;
     if (vu) { vu[2 * i] = v; vu[2 * i + 1] = u; }
     umin = u < umin ? u : umin; umax = u > umax ? u : umax;
     vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
   }
   win[0] = umin; win[1] = vmin; win[2] = umax; win[3] = vmax;
+  return true;
 }
 
 int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], const double K[9], double object_width_mm,
@@ -1118,6 +1144,8 @@ int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], cons
   // start-up allocations (first call / larger frame): pinned staging for a whole frame, its device mirror, outputs
   const size_t need = 256 + (size_t)H * W * 5 + 64;
   if (need > c->trk_bytes) {
+    DeviceGuard dg(c->device);                     //  staging buffers belong to the context's device, whatever the caller's current one
+    if (dg.err != hipSuccess) return hipfail(dg.err, "hipSetDevice");
     HIPCHK(hipDeviceSynchronize());
     if (c->trk_host) HIPCHK(hipHostFree(c->trk_host));
     if (c->trk_dev) HIPCHK(hipFree(c->trk_dev));
@@ -1127,6 +1155,8 @@ int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], cons
     c->trk_bytes = need;
   }
   if (!c->trk_out_host) {
+    DeviceGuard dg(c->device);
+    if (dg.err != hipSuccess) return hipfail(dg.err, "hipSetDevice");
     // pose | trans | rot | completion word in MAPPED pinned host memory: the tail kernel writes them across the bus itself and the
     // host polls the word -- no device-to-host copy, no stream wake-up on the per-frame critical path
     HIPCHK(hipHostMalloc((void**)&c->trk_out_host, 256, hipHostMallocMapped));
@@ -1140,8 +1170,11 @@ int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], cons
   // predict.py:231-235: bbox of the previous pose (host float64, round half to even) -> crop window of image B;
   // :201-206: the same with the y axis flipped -> the renderer's window
   int32_t winB[4], winA[4], vu[8];
-  bbox_window(prev_pose, K, object_width_mm, 1000.0, winB, vu);
-  bbox_window(prev_pose, K, object_width_mm, -1000.0, winA, nullptr);
+  // an object at or behind the camera plane has no crop window (the reference's compute_bbox divides by z and its crop comes out
+  // empty or mirrored; predict.py never gets there): refuse instead of running the frame
+  if (!(prev_pose[11] > 0) || !bbox_window(prev_pose, K, object_width_mm, 1000.0, winB, vu) ||
+      !bbox_window(prev_pose, K, object_width_mm, -1000.0, winA, nullptr))
+    return fail(SE3TN_E_ARG, "se3tn_on_track: pose is not in front of the camera (z <= 0 or not finite)");
   if (winB[2] <= winB[0] || winB[3] <= winB[1]) return fail(SE3TN_E_ARG, "se3tn_on_track: empty crop window (pose behind the camera?)");
   // image A first: its four launches run on the device while the host stages the frame
   uint8_t* rA = rgbA_dev ? rgbA_dev : c->trk_rgbA;
@@ -1190,7 +1223,7 @@ int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], cons
   a.split = c->prec == SE3TN_PREC_F16X3 ? 1 : 0;
   a.overflow = c->overflow; a.offset_rule = c->offset_rule;
   c->in_split[0] = c->in_split[1] = a.split;
-  HIPCHK(launch_preprocess(a, st));
+  if (const hipError_t e = launch_preprocess(a, st)) { (void)hipStreamSynchronize(c->trk_copy_stream); return hipfail(e, "launch_preprocess"); }
   const double t3 = trace ? now() : 0.0;
   float* trans_d = (float*)(c->trk_out_dev + 128);
   float* rot_d = (float*)(c->trk_out_dev + 144);
@@ -1201,7 +1234,10 @@ int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], cons
   c->tail_flag = poll ? flag_d : nullptr;
   const int rc_inf = se3tn_infer(c, c->inA, c->inB, 1, SE3TN_NHWC, trans_d, rot_d, (const double*)c->trk_dev, (double*)c->trk_out_dev, stream);
   c->tail_flag = nullptr;
-  if (rc_inf) return rc_inf;
+  if (rc_inf) {   // the staged frame is still travelling: the next call would overwrite the pinned buffer under the copy
+    (void)hipStreamSynchronize(c->trk_copy_stream);
+    return rc_inf;
+  }
   const double t4 = trace ? now() : 0.0;
   bool seen = false;
   if (poll) {   // 5 ms of polling covers every healthy frame; anything slower (or a fault) falls through to the stream wait

@@ -421,7 +421,9 @@ __device__ __forceinline__ void store_agent_scope(float* p, const float4 v) {
 }
 
 #ifndef SE3TN_SPLITK_WT
-#define SE3TN_SPLITK_WT 0   // 1: partial sums written through the L2 (any XCD may read them); 0: left in the tile's own XCD's L2
+#define SE3TN_SPLITK_WT 1   // 1 (shipped): partial sums written through the L2 and device-scope counters -- correct under ANY workgroup ->
+                            // XCD mapping (CU masks, other partition modes: ADVICE r5); 0 (measurement builds only, EXPERIMENTS item 41):
+                            // left in the tile's own XCD's L2, which ASSUMES blockIdx % 8 is the XCD
 #endif
 // the arrival counters: device scope (memory side) with write-through partial sums, the XCD's own L2 otherwise
 #if SE3TN_SPLITK_WT

@@ -110,9 +110,9 @@ class Tracker:
         self._trans = self._out[ms * 128:ms * 140].view(torch.float32).view(ms, 3)
         self._rot = self._out[ms * 140:ms * 152].view(torch.float32).view(ms, 3)
         self.last_prediction = None
-        # optional hipGraph replay of the ~25 dependent launches of a frame on a dedicated stream (the
-        # null stream cannot be captured).  Off by default: measured 0.47 ms/frame with vs 0.44 without
-        # (the kernels are 10-30 us each and the eager launches already run ahead of the device)
+        # optional hipGraph replay of the ~20 dependent launches of a frame on a dedicated stream (the
+        # null stream cannot be captured).  Off by default: measured 0.213 ms/frame with vs 0.194 without
+        # (profiles/EXPERIMENTS.md item 54: the kernels are 5-15 us each and the eager launches already run ahead of the device)
         self._stream = torch.cuda.Stream(device=dev) if use_graphs else None
         if use_graphs:
             self.engine.enable_graphs(True)

@@ -87,37 +87,134 @@ def calibrated_weights(seed, mesh, seq, K, numpy_rule="numpy1"):
     return sd
 
 
+class RandomInitProblem:
+    """oracle/closed_loop.py's stand-in: random-init weights with calibrated FC biases, a random-colour sphere, structured frames that
+    do NOT contain the object, rotation fed back, translation step carried on the anchor trajectory."""
+    kind = "random_init"
+
+    def __init__(self, seed, regime, sd=None, mesh=None, subdiv=5):
+        from . import raster_oracle as R
+        self.seed, self.regime = seed, regime
+        self.mesh = mesh if mesh is not None else R.icosphere(subdiv, 0.06, 0)
+        self.K = camera_matrix()
+        self.mean, self.std = Fx.mean_std(0)
+        self.tn, self.rn = CL.REGIMES[regime]
+        self.object_width = CL.OBJECT_WIDTH_MM
+        self.seq = CL._frames()
+        self.sd = sd if sd is not None else calibrated_weights(seed, self.mesh, self.seq, self.K)
+        self.s = track_setup(seed)
+
+    def spec(self):
+        return dict(kind=self.kind, seed=self.seed, regime=self.regime, sd={k: v.numpy() for k, v in self.sd.items()},
+                    mesh={k: np.asarray(v) for k, v in self.mesh.items()})
+
+    def frame(self, f):
+        return self.seq[(f + self.s["frame_offset"]) % CL.N_DISTINCT_FRAMES]
+
+    def initial_pose(self):
+        return initial_pose(self.seed)
+
+    def next_pose(self, P, Q, f):
+        return next_pose(P, Q, f, self.s["phase"])
+
+    def ground_truth(self, f):
+        return None
+
+
+class SynthTrackProblem:
+    """oracle/synth_track.py: an object that IS in the frames, ground-truth poses, weights trained on it (tests/golden/
+    synth_tracker.npz) -- the loop of predict.py:416-420 exactly: prev_pose <- on_track(prev_pose, frame), started from the
+    ground-truth pose of frame 0 (predict.py:404-409), no anchor."""
+    kind = "synth"
+
+    def __init__(self, seed, sequence, weights=None):
+        from . import synth_track as ST
+        self.seed, self.regime = seed, "ycb_video_5deg"
+        self.mesh = ST.make_object()
+        self.K = camera_matrix()
+        self.tn, self.rn = ST.TRANS_NORMALIZER, ST.ROT_NORMALIZER
+        self.object_width = ST.OBJECT_WIDTH_MM
+        self.sequence_path = sequence if isinstance(sequence, str) else None
+        self.sequence = ST.Sequence.load(sequence) if isinstance(sequence, str) else sequence
+        self.weights_path = weights or default_synth_weights()
+        self.sd, self.mean, self.std, self.weights_info = load_synth_weights(self.weights_path)
+        self.gt = [ST.gt_pose(seed, f) for f in range(len(self.sequence))]
+
+    def spec(self):
+        assert self.sequence_path, "save the sequence first (Sequence.save) so that the workers can load it"
+        return dict(kind=self.kind, seed=self.seed, sequence=self.sequence_path, weights=self.weights_path)
+
+    def frame(self, f):
+        return self.sequence.frame(f + 1)                 # iteration f estimates the pose of camera frame f + 1 from that of frame f
+
+    def initial_pose(self):
+        return self.gt[0].copy()
+
+    def next_pose(self, P, Q, f):
+        G = self.gt[f + 1]
+        if np.linalg.norm(Q[:3, 3] - G[:3, 3]) > 0.05 or not np.isfinite(Q).all():     # lost: re-detected at the ground truth (counted)
+            return G.copy(), 1
+        return Q.copy(), 0
+
+    def ground_truth(self, f):
+        return self.gt[f]
+
+
+def default_synth_weights():
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "synth_tracker.npz")
+
+
+def load_synth_weights(path):
+    """(state_dict, mean [8], std [8], info) of the trained stand-in: O.make_state_dict(base_seed) with the trained subset (stored
+    as float16 values) written over it -- scripts/train_synth_tracker.py"""
+    import torch
+    z = np.load(path)
+    sd = O.make_state_dict(int(z["base_seed"]))
+    n = 0
+    for k in z.files:
+        if k.startswith("w:"):
+            assert sd[k[2:]].shape == z[k].shape, k
+            sd[k[2:]] = torch.from_numpy(z[k].astype(np.float32))
+            n += 1
+    info = dict(trained_tensors=n, held_out=[float(v) for v in z["val"]] if "val" in z.files else None)
+    return sd, np.asarray(z["mean"], np.float64), np.asarray(z["std"], np.float64), info
+
+
+def problem_from_spec(spec):
+    import torch
+    if spec["kind"] == "random_init":
+        sd = {k: torch.from_numpy(np.array(v)) for k, v in spec["sd"].items()}
+        return RandomInitProblem(spec["seed"], spec["regime"], sd=sd, mesh=spec["mesh"])
+    return SynthTrackProblem(spec["seed"], spec["sequence"], spec["weights"])
+
+
 def oracle_track(job):
-    """Worker (spawned process, CPU only): the oracle's OWN closed loop.  job: sd (numpy arrays), mesh, K, regime, seed,
-    frames, numpy_rule, threads, images (path of the other track's image A stack, or None).  Returns poses fed in [F+1,4,4],
-    outputs [F,6], bboxes [F,8], per-frame differing image-A pixels vs the other track, reinits, seconds.
+    """Worker (spawned process, CPU only): the oracle's OWN closed loop on job["problem"] (a Problem.spec()).  Other keys: frames,
+    numpy_rule, threads, images (path of the other track's image A stack, or None).  Returns poses fed in [F+1,4,4], outputs
+    [F,6], bboxes [F,8], per-frame differing image-A pixels vs the other track, reinits, seconds.
     `variant` = "channels_last" / `save_to`: the CONTROL -- the same reference arithmetic (torch-CPU) with the network's inputs in
     the other memory format, i.e. another summation order inside the convolutions (1.2e-6 on the outputs); its
     images are written out for the other side's pixel count."""
     import torch
     torch.set_num_threads(int(job.get("threads", 2)))
     t0 = time.time()
-    sd = {k: torch.from_numpy(np.array(v)) for k, v in job["sd"].items()}
-    om = CL.oracle_mesh(job["mesh"])
-    K = np.asarray(job["K"], np.float64)
-    mean, std = Fx.mean_std(0)
-    tn, rn = CL.REGIMES[job["regime"]]
-    s = track_setup(job["seed"])
-    seq = CL._frames()
+    pb = problem_from_spec(job["problem"])
+    sd, K, mean, std, tn, rn, width = pb.sd, pb.K, pb.mean, pb.std, pb.tn, pb.rn, pb.object_width
+    om = CL.oracle_mesh(pb.mesh)
     other = None
     if job.get("images"):
         other = (np.load(job["images"] + ".rgb.npy", mmap_mode="r"), np.load(job["images"] + ".depth.npy", mmap_mode="r"))
     F = int(job["frames"])
-    P = initial_pose(job["seed"])
+    P = pb.initial_pose()
     poses, outs, bboxes, px, reinits = [P.copy()], [], [], [], 0
     keep_rgb, keep_depth = [], []
     variant = job.get("variant")                   # None | "channels_last": the control (the reference path against itself)
     rule = job.get("numpy_rule", "numpy1")
     for f in range(F):
-        rgb, depth = seq[(f + s["frame_offset"]) % CL.N_DISTINCT_FRAMES]
-        rgbA, depthA = CL.oracle_image_A(om, P, K, CL.OBJECT_WIDTH_MM, rule)
+        rgb, depth = pb.frame(f)
+        rgbA, depthA = CL.oracle_image_A(om, P, K, width, rule)
         # O.on_track, spelled out so that the control can change the memory format of the network's inputs
-        bb = O.compute_bbox(P, K, CL.OBJECT_WIDTH_MM, scale=(1000, 1000, 1000))
+        bb = O.compute_bbox(P, K, width, scale=(1000, 1000, 1000))
         rgbB, depthB = O.crop_bbox(rgb, depth, bb, (rgbA.shape[1], rgbA.shape[0]))
         a, b = O.process_data(rgbA, depthA, P, rgbB, depthB, mean, std, rule)
         A, B = torch.from_numpy(a)[None], torch.from_numpy(b)[None]
@@ -132,28 +229,34 @@ def oracle_track(job):
             keep_rgb.append(rgbA); keep_depth.append(depthA)
         outs.append(np.r_[aux["trans"], aux["rot"]])
         bboxes.append(np.asarray(aux["bbox"]).reshape(-1))
-        P, r = next_pose(P, Q, f, s["phase"])
+        P, r = pb.next_pose(P, Q, f)
         reinits += r
         poses.append(P.copy())
     if job.get("save_to"):
         np.save(job["save_to"] + ".rgb.npy", np.array(keep_rgb))
         np.save(job["save_to"] + ".depth.npy", np.array(keep_depth))
     return dict(poses=np.array(poses), outs=np.array(outs), bboxes=np.array(bboxes), px=np.array(px, np.int64),
-                reinits=reinits, seconds=time.time() - t0, regime=job["regime"], seed=job["seed"])
+                reinits=reinits, seconds=time.time() - t0, regime=pb.regime, seed=pb.seed)
 
 
-def hip_track(trk, regime, seed, frames, images_path=None):
-    """The drop-in Tracker's own closed loop (one se3tn_on_track call per frame).  Image A of every frame is read back
-    (for the pixel comparison only) and written to `images_path`."""
-    s = track_setup(seed)
-    seq = CL._frames()
-    P = initial_pose(seed)
+def make_hip_tracker(se3, pb, max_samples=1):
+    trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=pb.object_width), pb.mean, pb.std, {"state_dict": pb.sd},
+                      trans_normalizer=pb.tn, rot_normalizer=pb.rn, max_samples=max_samples)
+    trk.renderer = se3.HipRenderer(trk.engine, pb.mesh)
+    assert np.array_equal(trk.K, pb.K)
+    return trk
+
+
+def hip_track(trk, pb, frames, images_path=None):
+    """The drop-in Tracker's own closed loop on the problem (one se3tn_on_track call per frame).  Image A of every frame is read
+    back (for the pixel comparison only) and written to `images_path`."""
+    P = pb.initial_pose()
     poses, outs, bboxes, reinits = [P.copy()], [], [], 0
     rgbs = np.empty((frames, 176, 176, 3), np.uint8) if images_path else None
     deps = np.empty((frames, 176, 176), np.uint16) if images_path else None
     t_on = 0.0
     for f in range(frames):
-        rgb, depth = seq[(f + s["frame_offset"]) % CL.N_DISTINCT_FRAMES]
+        rgb, depth = pb.frame(f)
         t0 = time.perf_counter()
         Q = trk.on_track(P, rgb, depth)
         t_on += time.perf_counter() - t0
@@ -163,7 +266,7 @@ def hip_track(trk, regime, seed, frames, images_path=None):
         if images_path:
             rgbs[f] = trk.renderer.rgb.cpu().numpy()
             deps[f] = trk.renderer.depth.cpu().numpy().view(np.uint16)
-        P, r = next_pose(P, Q, f, s["phase"])
+        P, r = pb.next_pose(P, Q, f)
         reinits += r
         poses.append(P.copy())
     if images_path:
@@ -282,51 +385,71 @@ def camera_matrix():
     return np.array([[c["focalX"], 0, c["centerX"]], [0, c["focalY"], c["centerY"]], [0, 0, 1.0]])
 
 
+def _run_pairs(se3, problems, frames, nw, threads, control_keys, metrics):
+    """problems: {key: Problem}.  Runs the HIP track of every problem, the oracle track (and, for control_keys, the channels-last
+    control track) in worker processes; returns {key: (hip, oracle, control | None)}."""
+    tmp = tempfile.mkdtemp(prefix="se3tn_free_")
+    futures, hip = {}, {}
+    pool = _pool(nw)
+    try:
+        for key, pb in problems.items():
+            trk = make_hip_tracker(se3, pb)
+            path = os.path.join(tmp, "t%d" % len(hip))
+            hip[key] = hip_track(trk, pb, frames, path)
+            job = dict(problem=pb.spec(), frames=frames, numpy_rule=trk.engine.get_offset_rule(), threads=threads, images=path)
+            futures[(key, "oracle")] = pool.submit(oracle_track, job)
+            if key in control_keys:
+                futures[(key, "control")] = pool.submit(oracle_track, dict(job, variant="channels_last"))
+            del trk
+        res = {(key, kind): fut.result() for (key, kind), fut in futures.items()}
+    finally:
+        pool.shutdown(wait=True, cancel_futures=True)
+        for fn in os.listdir(tmp):
+            os.unlink(os.path.join(tmp, fn))
+        os.rmdir(tmp)
+    return {key: (hip[key], res[(key, "oracle")], res.get((key, "control"))) for key in problems}
+
+
+def _blocks(tracks, pts, metrics, label=lambda key: "seed_%d" % key):
+    """per-pair comparison blocks: HIP vs oracle, oracle vs its channels-last self (control), HIP vs that control track"""
+    per, ctl, hc = {}, {}, {}
+    for key, (h, o, c) in tracks.items():
+        r = compare_tracks(h, o, pts, metrics)
+        r["hip_ms_per_frame"] = round(h["ms_per_frame"], 4)
+        r["oracle_seconds"] = round(o["seconds"], 1)
+        per[label(key)] = r
+        if c is not None:
+            c = dict(c)
+            hc[label(key)] = compare_tracks(h, c, pts, metrics)
+            c.pop("px")                                    # (its pixel counts are against the HIP images)
+            ctl[label(key)] = compare_tracks(o, c, pts, metrics)
+    blk = dict(summarise(per), tracks_detail=per)
+    if ctl:
+        blk["control_oracle_vs_oracle_channels_last"] = dict(summarise(ctl), tracks_detail=ctl)
+        blk["hip_vs_oracle_channels_last"] = dict(summarise(hc), tracks_detail=hc)
+    return blk
+
+
 def run_free(se3, frames=1000, seeds=(0, 1, 2), regimes=None, subdiv=5, workers=None, metrics=None, control_seeds=(0,)):
-    """The `free_running` block: for every regime and seed, the HIP tracker's own closed loop and the oracle's own closed
-    loop over the same `frames` camera frames from the same start; for `control_seeds` also the CONTROL: the oracle's closed loop
-    with channels-last network inputs (same reference arithmetic, another summation order) -- how far the reference path
-    separates from ITSELF.  See the module docstring."""
+    """The `free_running` block on the RANDOM-INIT stand-in: for every regime and seed, the HIP tracker's own closed loop and the
+    oracle's own closed loop over the same `frames` camera frames from the same start; for `control_seeds` also the CONTROL: the
+    oracle's closed loop with channels-last network inputs (same reference arithmetic, another summation order) -- how far the
+    reference path separates from ITSELF.  See the module docstring."""
     from . import raster_oracle as R
     regimes = list(regimes or CL.REGIMES)
-    mean, std = Fx.mean_std(0)
     mesh = R.icosphere(subdiv, 0.06, 0)
-    mesh_np = {k: np.asarray(v) for k, v in mesh.items()}
-    seq = CL._frames()
     metrics = metrics or getattr(se3, "metrics", None)
     pts = model_points_of(mesh, se3)
     K = camera_matrix()
     njobs = len(seeds) * len(regimes) + len(control_seeds) * len(regimes)
     nw, threads = (workers, 2) if workers else default_workers(njobs)
     t_start = time.time()
-    tmp = tempfile.mkdtemp(prefix="se3tn_free_")
-    results, control, futures, hip = {}, {}, {}, {}
-    pool = _pool(nw)
-    try:
-        for seed in seeds:
-            sd = calibrated_weights(seed, mesh, seq, K)
-            sd_np = {k: v.numpy() for k, v in sd.items()}
-            for regime in regimes:
-                tn, rn = CL.REGIMES[regime]
-                trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=CL.OBJECT_WIDTH_MM), mean, std, {"state_dict": sd},
-                                  trans_normalizer=tn, rot_normalizer=rn, max_samples=1)
-                trk.renderer = se3.HipRenderer(trk.engine, mesh)
-                assert np.array_equal(trk.K, K)
-                path = os.path.join(tmp, "%s_%d" % (regime, seed))
-                hip[(regime, seed)] = hip_track(trk, regime, seed, frames, path)
-                job = dict(sd=sd_np, mesh=mesh_np, K=K, regime=regime, seed=seed, frames=frames,
-                           numpy_rule=trk.engine.get_offset_rule(), threads=threads, images=path)
-                futures[(regime, seed, "oracle")] = pool.submit(oracle_track, job)
-                if seed in control_seeds:
-                    futures[(regime, seed, "control")] = pool.submit(oracle_track, dict(job, variant="channels_last"))
-                del trk
-        for (regime, seed, kind), fut in futures.items():
-            (results if kind == "oracle" else control)[(regime, seed)] = fut.result()
-    finally:
-        pool.shutdown(wait=True, cancel_futures=True)
-        for fn in os.listdir(tmp):
-            os.unlink(os.path.join(tmp, fn))
-        os.rmdir(tmp)
+    problems = {}
+    for seed in seeds:
+        sd = calibrated_weights(seed, mesh, CL._frames(), K)
+        for regime in regimes:
+            problems[(regime, seed)] = RandomInitProblem(seed, regime, sd=sd, mesh=mesh)
+    tracks = _run_pairs(se3, problems, frames, nw, threads, {(r, s) for r in regimes for s in control_seeds}, metrics)
     out = {"what": "two INDEPENDENT closed loops per (regime, seed) over the same frames from the same start: the HIP tracker feeds back "
                    "its own pose and renders its own image A, the CPU oracle feeds back ITS own pose and renders its own image A "
                    "(oracle/free_run.py).  `control`: the oracle against ITSELF with channels-last network inputs (the same torch-CPU "
@@ -336,21 +459,66 @@ def run_free(se3, frames=1000, seeds=(0, 1, 2), regimes=None, subdiv=5, workers=
            "frames": frames, "seeds": list(seeds), "control_seeds": list(control_seeds), "oracle_workers": nw,
            "oracle_threads_per_worker": threads, "regimes": {}}
     for regime in regimes:
-        per, ctl, hc = {}, {}, {}
-        for seed in seeds:
-            c = compare_tracks(hip[(regime, seed)], results[(regime, seed)], pts, metrics)
-            c["hip_ms_per_frame"] = round(hip[(regime, seed)]["ms_per_frame"], 4)
-            c["oracle_seconds"] = round(results[(regime, seed)]["seconds"], 1)
-            per["seed_%d" % seed] = c
-            if (regime, seed) in control:
-                o = dict(control[(regime, seed)])
-                hc["seed_%d" % seed] = compare_tracks(hip[(regime, seed)], o, pts, metrics)       # HIP vs the control track
-                o.pop("px")                                                                       # (its pixel counts are against the HIP images)
-                ctl["seed_%d" % seed] = compare_tracks(results[(regime, seed)], o, pts, metrics)  # oracle vs oracle (channels last)
-        blk = dict(summarise(per), tracks_detail=per)
-        if ctl:
-            blk["control_oracle_vs_oracle_channels_last"] = dict(summarise(ctl), tracks_detail=ctl)
-            blk["hip_vs_oracle_channels_last"] = dict(summarise(hc), tracks_detail=hc)
-        out["regimes"][regime] = blk
+        out["regimes"][regime] = _blocks({s: tracks[(regime, s)] for s in seeds}, pts, metrics)
+    out["seconds"] = round(time.time() - t_start, 1)
+    return out
+
+
+def against_ground_truth(track, pb, pts, metrics):
+    """ADD / ADD-S of a track against the sequence's ground truth and their AUC (eval_ycb.py:45-119: VOCap up to 0.1 m, x100)"""
+    F = len(track["outs"])
+    add = np.array([metrics.add(track["poses"][f], pb.ground_truth(f), pts) for f in range(1, F + 1)])
+    adi = np.array([metrics.adi(track["poses"][f], pb.ground_truth(f), pts, workers=1) for f in range(1, F + 1)])
+    return {"add_auc": metrics.auc(add), "adds_auc": metrics.auc(adi), "add_mm_median": float(np.median(add) * 1e3), "add_mm_max": float(add.max() * 1e3),
+            "adds_mm_median": float(np.median(adi) * 1e3), "adds_mm_max": float(adi.max() * 1e3), "reinits": int(track["reinits"])}
+
+
+def run_tracked(se3, frames=1000, seeds=(0, 1, 2), workers=None, metrics=None, control_seeds=(0,), weights=None):
+    """The `free_running` block on the synthetic tracking problem WITH ground truth and trained stand-in weights
+    (oracle/synth_track.py, tests/golden/synth_tracker.npz): the loop of predict.py:416-420 unmodified on both sides -- started at
+    the ground-truth pose of frame 0, prev_pose <- on_track(prev_pose, frame) -- plus what configs[2] reports: ADD / ADD-S AUC of each
+    track against the ground truth and the Hz of the HIP track."""
+    from . import synth_track as ST
+    metrics = metrics or getattr(se3, "metrics", None)
+    K = camera_matrix()
+    njobs = len(seeds) + len(control_seeds)
+    nw, threads = (workers, 2) if workers else default_workers(njobs)
+    t_start = time.time()
+    tmp = tempfile.mkdtemp(prefix="se3tn_seq_")
+    problems = {}
+    try:
+        with _pool(nw * threads) as pool:                   # the object patches of every frame (CPU renders), in parallel
+            for seed in seeds:
+                seq = ST.make_sequence(seed, frames + 1, K, pool)
+                path = os.path.join(tmp, "seq_%d.npz" % seed)
+                seq.save(path)
+                problems[seed] = SynthTrackProblem(seed, path, weights)
+        t_seq = time.time() - t_start
+        tracks = _run_pairs(se3, problems, frames, nw, threads, set(control_seeds), metrics)
+    finally:
+        for fn in os.listdir(tmp):
+            os.unlink(os.path.join(tmp, fn))
+        os.rmdir(tmp)
+    pb0 = problems[seeds[0]]
+    pts = model_points_of(pb0.mesh, se3)
+    out = {"what": "synthetic tracking problem with ground truth (oracle/synth_track.py): an ellipsoid with a smooth colour pattern moves "
+                   "4-7 mm and 1-2.5 degrees per frame in front of structured backgrounds; stand-in weights TRAINED on that problem "
+                   "(tests/golden/synth_tracker.npz: the pretrained YCB weights are not available offline); the loop of predict.py:"
+                   "416-420 unmodified: start at the ground-truth pose of frame 0, prev_pose <- on_track(prev_pose, frame).  Two "
+                   "INDEPENDENT runs of that loop -- HIP tracker / CPU oracle -- and the oracle against itself (channels-last control)",
+           "frames": frames, "seeds": list(seeds), "control_seeds": list(control_seeds), "oracle_workers": nw,
+           "oracle_threads_per_worker": threads, "trans_normalizer": pb0.tn, "rot_normalizer_deg": round(pb0.rn * 180 / np.pi, 3),
+           "weights": pb0.weights_info, "sequence_seconds": round(t_seq, 1)}
+    out.update(_blocks(tracks, pts, metrics))
+    gt = {}
+    for seed, (h, o, c) in tracks.items():
+        g = {"hip": against_ground_truth(h, problems[seed], pts, metrics), "oracle": against_ground_truth(o, problems[seed], pts, metrics)}
+        if c is not None:
+            g["oracle_channels_last"] = against_ground_truth(c, problems[seed], pts, metrics)
+        g["adds_auc_hip_minus_oracle"] = g["hip"]["adds_auc"] - g["oracle"]["adds_auc"]
+        g["add_auc_hip_minus_oracle"] = g["hip"]["add_auc"] - g["oracle"]["add_auc"]
+        gt["seed_%d" % seed] = g
+    out["against_ground_truth"] = gt
+    out["hz_hip"] = round(1000.0 / float(np.median([h["ms_per_frame"] for h, _, _ in tracks.values()])), 1)
     out["seconds"] = round(time.time() - t_start, 1)
     return out

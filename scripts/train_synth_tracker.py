@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Stand-in weights for the closed-loop tests: se(3)-TrackNet trained (torch-CPU autograd through the oracle's forward) on the
+synthetic tracking problem of oracle/synth_track.py, so that the loop of predict.py:416-420 is contractive as it is with the
+reference's pretrained weights (which are not available offline).  TEST-FIXTURE GENERATOR, not product code; training itself is
+out of the hot path's scope.
+
+Only a SUBSET of the state_dict is trained (stems, the 64-channel blocks, convAB1, every BN affine, the two FC layers); every
+other tensor stays O.make_state_dict(BASE_SEED).  The fixture tests/golden/synth_tracker.npz holds the trained tensors rounded to
+float16 (both sides load the same float32 values), the mean / std of the training set and the held-out errors.
+
+    python scripts/train_synth_tracker.py --samples 6000 --steps 900 [--out tests/golden/synth_tracker.npz]"""
+import argparse
+import os
+import re
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+BASE_SEED = 0
+TRAINABLE = r"^(convA1|convB1|convA2|convB2|convB3|convAB1)\.|\.(bn1|bn2|1)\.(weight|bias)$|^(trans_out|rot_out)\."
+
+
+def gen_data(n, K, workers, per_job=100, first_seed=0):
+    from oracle import free_run as FR, synth_track as ST
+    jobs = [dict(seed=first_seed + j, n=min(per_job, n - j * per_job), K=K) for j in range((n + per_job - 1) // per_job)]
+    with FR._pool(workers) as pool:
+        parts = list(pool.map(ST.training_samples, jobs))
+    return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--samples", type=int, default=6000)
+    ap.add_argument("--val", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=900)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--lr", type=float, default=2e-3)
+    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--data", default="/tmp/synth_train.npz")
+    ap.add_argument("--out", default="tests/golden/synth_tracker.npz")
+    ap.add_argument("--resume", default=None)
+    args = ap.parse_args()
+    import torch
+    from oracle import free_run as FR, se3_oracle as O, synth_track as ST
+    torch.set_num_threads(args.threads)
+    K = FR.camera_matrix()
+    if os.path.exists(args.data):
+        z = np.load(args.data)
+        data = {k: z[k] for k in z.files}
+    else:
+        t0 = time.time()
+        data = gen_data(args.samples + args.val, K, args.workers)
+        np.savez(args.data, **data)
+        print("generated %d samples in %.0f s" % (len(data["zA"]), time.time() - t0), flush=True)
+    n = len(data["zA"]) - args.val
+    T = {k: torch.from_numpy(v) for k, v in data.items()}
+
+    def tensors(idx):
+        dA = ST.offset_depth_torch(T["depthA"][idx].to(torch.int32), T["zA"][idx], torch)
+        dB = ST.offset_depth_torch(T["depthB"][idx].to(torch.int32), T["zA"][idx], torch)
+        A = torch.cat([T["rgbA"][idx].to(torch.float32), dA[..., None]], 3)
+        B = torch.cat([T["rgbB"][idx].to(torch.float32), dB[..., None]], 3)
+        return A, B
+
+    # mean / std per channel over (a sample of) the training set, A then B (mean.npy / std.npy layout, predict.py:657-658)
+    A, B = tensors(torch.arange(0, min(n, 1000)))
+    mean = torch.cat([A.mean((0, 1, 2)), B.mean((0, 1, 2))]).double().numpy()
+    std = torch.cat([A.std((0, 1, 2)), B.std((0, 1, 2))]).double().numpy()
+    print("mean", mean.round(2), "std", std.round(2), flush=True)
+    mean_t, std_t = torch.from_numpy(mean).float(), torch.from_numpy(std).float()
+
+    def batch(idx):
+        A, B = tensors(idx)
+        A = ((A - mean_t[:4]) / std_t[:4]).permute(0, 3, 1, 2).contiguous()
+        B = ((B - mean_t[4:]) / std_t[4:]).permute(0, 3, 1, 2).contiguous()
+        return A, B, T["trans"][idx], T["rot"][idx]
+
+    sd = O.make_state_dict(BASE_SEED)
+    for h in ("trans_out", "rot_out"):        # start the (trainable) FC layers small: tanh away from saturation
+        sd[h + ".0.weight"] = sd[h + ".0.weight"] * 0.02
+        sd[h + ".0.bias"] = sd[h + ".0.bias"] * 0.0
+    if args.resume:
+        z = np.load(args.resume)
+        for k in z.files:
+            if k.startswith("w:"):
+                sd[k[2:]] = torch.from_numpy(z[k].astype(np.float32))
+    pat = re.compile(TRAINABLE)
+    params = []
+    for k, v in sd.items():
+        if v.dtype == torch.float32 and pat.search(k) and "running" not in k:
+            v.requires_grad_(True)
+            params.append(v)
+    print("trainable tensors %d, parameters %d" % (len(params), sum(p.numel() for p in params)), flush=True)
+    fwd = O.forward.__wrapped__
+    opt = torch.optim.Adam(params, lr=args.lr)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=args.lr, total_steps=args.steps, pct_start=0.15)
+    rng = np.random.default_rng(0)
+    val_idx = torch.arange(n, n + args.val)
+
+    def evaluate():
+        with torch.no_grad():
+            et, er = [], []
+            for i in range(0, args.val, 50):
+                A, B, lt, lr_ = batch(val_idx[i:i + 50])
+                o = fwd(sd, A, B)
+                et.append((o["trans"] - lt).abs())
+                er.append((o["rot"] - lr_).abs())
+            et, er = torch.cat(et), torch.cat(er)
+            lt, lr_ = T["trans"][val_idx], T["rot"][val_idx]
+            # residual after one step relative to the residual before it: < 1 means the loop contracts
+            ratio_t = float(et.norm(dim=1).mean() / lt.norm(dim=1).mean())
+            ratio_r = float(er.norm(dim=1).mean() / lr_.norm(dim=1).mean())
+            return float(et.mean()), float(er.mean()), ratio_t, ratio_r
+
+    def save(path, val):
+        out = {"mean": mean, "std": std, "base_seed": BASE_SEED, "val": np.array(val), "trainable": TRAINABLE}
+        for k, v in sd.items():
+            if v.requires_grad:
+                out["w:" + k] = v.detach().numpy().astype(np.float16)
+        np.savez_compressed(path, **out)
+
+    t0 = time.time()
+    for step in range(args.steps):
+        idx = torch.from_numpy(rng.choice(n, args.batch, replace=False))
+        A, B, lt, lr_ = batch(idx)
+        o = fwd(sd, A, B)
+        loss_t = ((o["trans"] - lt) ** 2).mean()
+        loss_r = ((o["rot"] - lr_) ** 2).mean()
+        loss = loss_t + loss_r
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step()
+        if step % 10 == 0:
+            print("step %4d  loss trans %.4f rot %.4f   %.0f s" % (step, float(loss_t.detach()), float(loss_r.detach()), time.time() - t0), flush=True)
+        if step % 100 == 99 or step == args.steps - 1:
+            val = evaluate()
+            print("   val |d trans| %.4f |d rot| %.4f  residual ratio trans %.3f rot %.3f" % val, flush=True)
+            save(args.out, val)
+    print("saved", args.out, os.path.getsize(args.out), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -107,5 +107,6 @@ def test_closed_loop_f16x3_mode(se3):
 @pytest.mark.gpu
 def test_run_aggregates_both_regimes(se3):
     r = closed_loop.run(se3, frames=20, check=True, timing=True)
-    assert set(r["regimes"]) == set(closed_loop.REGIMES) and r["frames_checked"] == 40 and r["ok"], r
-    assert r["hz"] > 0 and "median_abs_trans_rot" in r and "max_abs_logit_diff" in r
+    psp = r["per_step_parity"]
+    assert set(r["regimes"]) == set(closed_loop.REGIMES) and psp["frames_checked"] == 40 and psp["teacher_forced"] and r["ok"], r
+    assert r["hz"] > 0 and "median_abs_trans_rot" in psp and "max_abs_logit_diff" in psp

@@ -12,10 +12,8 @@ from oracle import closed_loop as CL, fixtures as Fx, free_run as FR
 def cpu_tracks():
     from oracle import raster_oracle as R
     mesh = R.icosphere(3, 0.06, 0)
-    K = FR.camera_matrix()
-    sd = FR.calibrated_weights(0, mesh, CL._frames(), K)
-    job = dict(sd={k: v.numpy() for k, v in sd.items()}, mesh={k: np.asarray(v) for k, v in mesh.items()}, K=K,
-               regime="ycbineoat_30deg", seed=1, frames=5, threads=4)
+    pb = FR.RandomInitProblem(1, "ycbineoat_30deg", mesh=mesh)
+    job = dict(problem=pb.spec(), frames=5, threads=4)
     import os
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:

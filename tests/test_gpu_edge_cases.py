@@ -276,6 +276,36 @@ def test_hipgraph_replay_of_the_winograd_path(se3, n):
     assert torch.equal(got, tr) and not torch.equal(got, want[0])
 
 
+def test_hipgraph_follows_the_small_kernel_switch(se3):
+    """the graph key holds every switch that selects a kernel family.  With graphs on, se3tn_set_small_kernels(0)
+    after a capture must run the general kernels (bit-equal to eager with the switch off), not replay the batch-1 family's graph."""
+    sd = O.make_state_dict(0)
+    n = 2
+    eng = se3.Engine(0, n)
+    eng.load_state_dict(sd)
+    tr, ro = torch.empty((n, 3), device="cuda"), torch.empty((n, 3), device="cuda")
+    A, B = Fx.net_inputs(23, n)
+    Ac, Bc = A.cuda(), B.cuda()
+    want = {}
+    for on in (True, False):                       # eager results of both families
+        eng.set_small_kernels(on)
+        eng.infer(Ac, Bc, n, se3.NCHW, tr, ro)
+        want[on] = eng.logits(n).clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(want[True], want[False])          # the two families differ in summation order
+    st = torch.cuda.Stream()
+    eng.enable_graphs(True)
+    with torch.cuda.stream(st):
+        for on in (True, False, True, False):
+            eng.set_small_kernels(on)
+            for it in range(3):                    # eager, capture, replay -- under this setting's own key
+                eng.infer(Ac, Bc, n, se3.NCHW, tr, ro)
+                st.synchronize()
+                assert torch.equal(eng.logits(n), want[on]), (on, it)
+    eng.enable_graphs(False)
+    eng.set_small_kernels(True)
+
+
 def test_large_batch_192_matches_single_pairs(se3):
     """Maximum-size style check: a 192-pair call (3x BASELINE's batch; offsets beyond 2^31 bytes in the
     stem buffer) agrees pair-by-pair with single-pair calls, in both arithmetic modes."""
