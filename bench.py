@@ -16,7 +16,10 @@ The JSON line carries, besides the contract fields:
                 algorithmic (direct-convolution) rate is reported beside it as effective_vs_direct
   parity        the TIMED batch checked against the CPU oracle: all pairs, pre-processing bit-exact, (trans, rot)
                 and the composed pose against the north-star tolerances
-  track         300-frame closed-loop Tracker.on_track stand-in for configs[2] with per-frame oracle parity
+  track         300-frame closed-loop Tracker.on_track stand-in for configs[2]: `per_step_parity` (the oracle evaluated at the HIP
+                track's pose every frame) and `free_running` (two independent closed loops, HIP / oracle, 1000 frames x 3 seeds: on a
+                synthetic tracking problem with ground truth and trained stand-in weights -- ADD / ADD-S AUC of both tracks -- and
+                on the random-init stand-in, each with the oracle-vs-itself control)
   cpu_baseline  the oracle timed on this box's host cores (bounded sample)
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--stage full|net]
@@ -87,8 +90,14 @@ def main():
                          "streams / activation workspaces, so the HBM-bound passes of one step run under the MFMA-bound kernels "
                          "of the other; 1 = strictly one step at a time (reported as `single_stream` in any case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tracker-batch", action="store_true", help="skip the Tracker.on_track_batch leg (tracker_batch block)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed batch")
     ap.add_argument("--track-frames", type=int, default=300, help="closed-loop Tracker.on_track stand-in (0 = skip)")
+    ap.add_argument("--free-frames", type=int, default=1000,
+                    help="frames of the FREE-RUNNING two-track comparison on the synthetic tracking problem with ground truth and "
+                         "trained stand-in weights (track.free_running.synthetic_tracking_trained_weights; 0 = skip)")
+    ap.add_argument("--free-frames-random", type=int, default=1000,
+                    help="frames of the free-running comparison on the random-init stand-in (track.free_running.random_init; 0 = skip)")
     ap.add_argument("--exact-steps", action="store_true",
                     help="never extend the timed region beyond --steps (default: a region shorter than 1 s is re-run "
                          "with enough steps and BOTH are reported)")
@@ -661,6 +670,20 @@ def main():
         if world == 1 and args.track_frames > 0 and args.precision == "f32":
             from oracle import closed_loop
             out["track"] = closed_loop.run(se3, frames=args.track_frames, check=not args.no_parity)
+            if not args.no_parity and (args.free_frames > 0 or args.free_frames_random > 0):
+                # two INDEPENDENT closed loops (HIP tracker / CPU oracle), 3 seeds each, + the oracle-vs-itself control: what
+                # "same track" means (oracle/free_run.py); the oracle tracks run in worker processes on the host cores
+                from oracle import free_run
+                out["track"]["free_running"] = free_run.run_report(se3, args.free_frames, args.free_frames_random)
+        if world == 1 and args.track_frames > 0 and args.precision == "f32" and not args.no_tracker_batch:
+            # the path a many-tracks / many-objects deployment (configs[3] / [4]) calls per step: Tracker.on_track_batch, renderer- and
+            # PCIe-inclusive (frames start in host memory), with a pair-by-pair oracle check of the same configuration
+            from oracle import closed_loop
+            out["tracker_batch"] = {
+                "what": "Tracker.on_track_batch: n independent closed-loop tracks per call = host float64 bboxes + image A of all n poses "
+                        "rendered on the device + the n camera frames' crop windows staged from host memory and uploaded + both crops + "
+                        "network + pose update + read-back; wall clock per call, synthetic frames, random-init weights",
+                "sizes": {str(n): closed_loop.time_batch(se3, n, check_frames=0 if args.no_parity else 2) for n in (8, 21, 64)}}
         if args.layers:
             for n, ms in layers:
                 print("%-32s %8.3f ms" % (n, ms), file=sys.stderr)

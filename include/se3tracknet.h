@@ -262,6 +262,20 @@ int se3tn_on_track(se3tn_ctx* ctx, se3tn_mesh* mesh, const double prev_pose[16],
                    const uint8_t* rgb, const uint16_t* depth, int H, int W, uint8_t* rgbA_dev, uint16_t* depthA_dev,
                    double pose_out[16], float trans_out[3], float rot_out[3], int32_t bbox_vu[8], void* stream);
 
+/* ---- n tracks in ONE call ----------------------------------------------------------------------------- */
+/* The loop body of predict.py:217-296 for n INDEPENDENT (pose, camera frame) pairs of the same object -- several sequences /
+ * cameras / hypotheses advanced together (frames of one track are serial: this is where a batch comes from in deployment;
+ * Tracker.on_track_batch).  Per pair exactly se3tn_on_track's arithmetic: compute_bbox (host float64), image A of all n poses in
+ * FOUR rasteriser launches (grid.y = pose), the crop windows of the n frames staged through pinned memory in one copy, both crops of
+ * every pair, the network on n pairs, the pose update.  prev_poses [n,16] row-major; rgb / depth: n HOST pointers to uint8 [H,W,3] /
+ * uint16 [H,W] frames of one size (the same pointer may repeat).  rgbA_dev / depthA_dev: optional device buffers
+ * [n,176,176,3] / [n,176,176] that receive the images A (NULL: internal).  Outputs (host): pose_out [n,16], trans_out / rot_out
+ * [n,3] (may be NULL), bbox_vu [n,4,2] (may be NULL).  n <= max_batch of se3tn_create.  SYNCHRONOUS on `stream`; the first call
+ * (a larger n, mesh or frame) allocates. */
+int se3tn_on_track_batch(se3tn_ctx* ctx, se3tn_mesh* mesh, int n, const double* prev_poses, const double K[9], double object_width_mm,
+                         const uint8_t* const* rgb, const uint16_t* const* depth, int H, int W, uint8_t* rgbA_dev,
+                         uint16_t* depthA_dev, double* pose_out, float* trans_out, float* rot_out, int32_t* bbox_vu, void* stream);
+
 /* ---- live-camera front end: depth hole filling ---------------------------------------------------- */
 /* Utils.py:455-514 `fill_depth` as predict_ros.py:38-41 applies it to every depth frame before on_track:
  *     depth = fill_depth(depth_mm / 1e3, max_depth, extrapolate, blur_type);  out_mm = (depth * 1000).astype(uint16)

@@ -106,6 +106,13 @@ struct se3tn_ctx {
   // se3tn_on_track: pinned host staging [pose 128 B | frame window rgb | depth], its device mirror, device outputs and their pinned copy
   uint8_t* trk_host = nullptr; uint8_t* trk_dev = nullptr; size_t trk_bytes = 0;
   uint8_t* trk_out_dev = nullptr; uint8_t* trk_out_host = nullptr;   // ONE mapped pinned block: device address | host address
+  // se3tn_on_track_batch: instance table (pinned host + device), z-buffers, image A stack, staging, outputs -- grown at first use / larger n
+  int tb_cap = 0;
+  size_t tb_stage_bytes = 0;
+  RasterInstance *tb_inst_host = nullptr, *tb_inst_dev = nullptr;
+  unsigned long long* tb_zbuf = nullptr;
+  uint8_t *tb_rgbA = nullptr, *tb_stage_host = nullptr, *tb_stage_dev = nullptr, *tb_out_host = nullptr, *tb_out_dev = nullptr;
+  uint16_t* tb_depthA = nullptr;
   bool rearm_counters = false;                  // a failed launch sequence: clear tail_arrive / splitk_sem before the next one
   int* tail_arrive = nullptr;                   // [max_batch] arrival counters of tail_kernel's 16 workgroups per pair (zero between launches)
   int* tail_flag = nullptr; int tail_seq = 0;   // set around se3tn_on_track's infer: the tail kernel stores tail_seq to this (mapped) word
@@ -143,6 +150,11 @@ struct se3tn_mesh {
   int* big = nullptr;     // [1 + F] queue of large triangles (raster_queue_kernel)
   int* clipq = nullptr;   // [1 + F] queue of triangles that cross the frustum (raster_queue_kernel)
   int V = 0, F = 0;
+  // batched rasteriser scratch (se3tn_on_track_batch): batch_cap instances of vpost / vsnap / big / clipq
+  int batch_cap = 0;
+  float4* b_vpost = nullptr;
+  int4* b_vsnap = nullptr;
+  int *b_big = nullptr, *b_clipq = nullptr;
   // pyrender-style material (se3tn_mesh_set_texture): uv per vertex, RGB mip pyramid, Kd
   float* uv = nullptr;
   uint8_t* tex = nullptr;
@@ -408,6 +420,10 @@ void se3tn_destroy(se3tn_ctx* c) {
     for (void* b : {(void*)c->trk_dev, (void*)c->trk_rgbA, (void*)c->trk_depthA})
       if (b) (void)hipFree(b);
     if (c->zbuf) (void)hipFree(c->zbuf);
+    for (void* b : {(void*)c->tb_inst_host, (void*)c->tb_out_host, (void*)c->tb_stage_host})
+      if (b) (void)hipHostFree(b);
+    for (void* b : {(void*)c->tb_inst_dev, (void*)c->tb_zbuf, (void*)c->tb_rgbA, (void*)c->tb_depthA, (void*)c->tb_out_dev, (void*)c->tb_stage_dev})
+      if (b) (void)hipFree(b);
     if (c->fd_buf) (void)hipFree(c->fd_buf);
     for (int s = 0; s < c->slots; ++s)
       for (auto& e : c->evs[s]) (void)hipEventDestroy(e);
@@ -1018,7 +1034,8 @@ int se3tn_mesh_set_texture(se3tn_mesh* m, const float* uv, const uint8_t* rgb, i
 
 void se3tn_mesh_destroy(se3tn_mesh* m) {
   if (!m) return;
-  void* bufs[] = {m->verts, m->normals, m->colors, m->faces, m->vpost, m->vsnap, m->big, m->clipq, m->uv, m->tex};
+  void* bufs[] = {m->verts, m->normals, m->colors, m->faces, m->vpost, m->vsnap, m->big, m->clipq, m->uv, m->tex,
+                  m->b_vpost, m->b_vsnap, m->b_big, m->b_clipq};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete m;
@@ -1058,14 +1075,9 @@ int se3tn_set_small_kernels(se3tn_ctx* c, int on) {
 }
 int se3tn_get_small_kernels(const se3tn_ctx* c) { return c ? (c->small_kernels ? 1 : 0) : -1; }
 
-int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const double K[9], const int32_t window[4],
-                 uint8_t* rgb, uint16_t* depth, void* stream) {
-  if (!c || c->device < 0 || !m || !ob_in_cam || !K || !window || !rgb || !depth)
-    return fail(SE3TN_E_ARG, "se3tn_render: bad argument");
-  if (window[2] <= window[0] || window[3] <= window[1]) return fail(SE3TN_E_ARG, "se3tn_render: empty window");
-  RasterArgs a{};
-  raster_common(a, c, m, rgb, depth);
-  a.rw = RES; a.rh = RES; a.mode = 0;
+// The float32 uniforms of the reference's VispyRenderer for one pose / window: a.PV, a.light, a.dA, a.dB
+// (false: singular pose)
+static bool vispy_uniforms(RasterArgs& a, const double ob_in_cam[16], const double K[9], const int32_t window[4]) {
   // The float32 uniforms the reference uploads, formed as it forms them (float64 numpy, then the cast of the upload):
   // update_cam_mat (vispy_renderer.py:135-150): ortho (rounded to float32 FIRST, :146) . proj in float64 ...
   const double n = R_NEAR_D, f = R_FAR_D;
@@ -1099,9 +1111,21 @@ int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const 
       adjT[r][q] = R[r1][q1] * R[r2][q2] - R[r1][q2] * R[r2][q1];
     }
   const double det = R[0][0] * adjT[0][0] + R[0][1] * adjT[0][1] + R[0][2] * adjT[0][2];
-  if (det == 0.0) return fail(SE3TN_E_ARG, "se3tn_render: singular pose");
+  if (det == 0.0) return false;
   const double l[3] = {0.0, 0.1, -0.9};
   for (int r = 0; r < 3; ++r) a.light[r] = (float)((adjT[r][0] * l[0] + adjT[r][1] * l[1] + adjT[r][2] * l[2]) / det);
+  return true;
+}
+
+int se3tn_render(se3tn_ctx* c, se3tn_mesh* m, const double ob_in_cam[16], const double K[9], const int32_t window[4],
+                 uint8_t* rgb, uint16_t* depth, void* stream) {
+  if (!c || c->device < 0 || !m || !ob_in_cam || !K || !window || !rgb || !depth)
+    return fail(SE3TN_E_ARG, "se3tn_render: bad argument");
+  if (window[2] <= window[0] || window[3] <= window[1]) return fail(SE3TN_E_ARG, "se3tn_render: empty window");
+  RasterArgs a{};
+  raster_common(a, c, m, rgb, depth);
+  a.rw = RES; a.rh = RES; a.mode = 0;
+  if (!vispy_uniforms(a, ob_in_cam, K, window)) return fail(SE3TN_E_ARG, "se3tn_render: singular pose");
   HIPCHK(launch_raster(a, (hipStream_t)stream));
   return SE3TN_OK;
 }
@@ -1262,6 +1286,151 @@ int se3tn_on_track(se3tn_ctx* c, se3tn_mesh* m, const double prev_pose[16], cons
   if (trans_out) std::memcpy(trans_out, c->trk_out_host + 128, 12);
   if (rot_out) std::memcpy(rot_out, c->trk_out_host + 144, 12);
   if (bbox_vu) std::memcpy(bbox_vu, vu, sizeof(vu));
+  return SE3TN_OK;
+}
+
+// ---- n tracks per call -------------------------------------------------------------------------------------------------------
+// start-up allocations of se3tn_on_track_batch (first call, a larger n, a larger mesh or frame)
+static int reserve_track_batch(se3tn_ctx* c, se3tn_mesh* m, int n, size_t stage_bytes) {
+  if (n <= c->tb_cap && n <= m->batch_cap && stage_bytes <= c->tb_stage_bytes) return SE3TN_OK;
+  DeviceGuard dg(c->device);
+  if (dg.err != hipSuccess) return hipfail(dg.err, "hipSetDevice");
+  HIPCHK(hipDeviceSynchronize());
+  if (n > c->tb_cap) {
+    if (c->tb_inst_host) HIPCHK(hipHostFree(c->tb_inst_host));
+    if (c->tb_out_host) HIPCHK(hipHostFree(c->tb_out_host));
+    for (void* b : {(void*)c->tb_inst_dev, (void*)c->tb_zbuf, (void*)c->tb_rgbA, (void*)c->tb_depthA, (void*)c->tb_out_dev})
+      if (b) HIPCHK(hipFree(b));
+    c->tb_inst_host = nullptr; c->tb_out_host = nullptr; c->tb_inst_dev = nullptr; c->tb_zbuf = nullptr; c->tb_rgbA = nullptr;
+    c->tb_depthA = nullptr; c->tb_out_dev = nullptr; c->tb_cap = 0;
+    const int cap = n > c->max_batch ? n : c->max_batch;
+    HIPCHK(hipHostMalloc((void**)&c->tb_inst_host, sizeof(RasterInstance) * cap, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->tb_out_host, (size_t)cap * 160, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&c->tb_inst_dev, sizeof(RasterInstance) * cap));
+    HIPCHK(hipMalloc((void**)&c->tb_zbuf, sizeof(unsigned long long) * RES * RES * cap));
+    HIPCHK(hipMalloc((void**)&c->tb_rgbA, (size_t)RES * RES * 3 * cap));
+    HIPCHK(hipMalloc((void**)&c->tb_depthA, (size_t)RES * RES * 2 * cap));
+    HIPCHK(hipMalloc((void**)&c->tb_out_dev, (size_t)cap * 160));
+    c->tb_cap = cap;
+  }
+  if (n > m->batch_cap) {
+    for (void* b : {(void*)m->b_vpost, (void*)m->b_vsnap, (void*)m->b_big, (void*)m->b_clipq})
+      if (b) HIPCHK(hipFree(b));
+    m->b_vpost = nullptr; m->b_vsnap = nullptr; m->b_big = nullptr; m->b_clipq = nullptr; m->batch_cap = 0;
+    const int cap = n > c->max_batch ? n : c->max_batch;
+    HIPCHK(hipMalloc((void**)&m->b_vpost, sizeof(float4) * (size_t)m->V * cap));
+    HIPCHK(hipMalloc((void**)&m->b_vsnap, sizeof(int4) * (size_t)m->V * cap));
+    HIPCHK(hipMalloc((void**)&m->b_big, sizeof(int) * (size_t)(1 + m->F) * cap));
+    HIPCHK(hipMalloc((void**)&m->b_clipq, sizeof(int) * (size_t)(1 + m->F) * cap));
+    m->batch_cap = cap;
+  }
+  if (stage_bytes > c->tb_stage_bytes) {
+    if (c->tb_stage_host) HIPCHK(hipHostFree(c->tb_stage_host));
+    if (c->tb_stage_dev) HIPCHK(hipFree(c->tb_stage_dev));
+    c->tb_stage_host = nullptr; c->tb_stage_dev = nullptr; c->tb_stage_bytes = 0;
+    HIPCHK(hipHostMalloc((void**)&c->tb_stage_host, stage_bytes, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&c->tb_stage_dev, stage_bytes));
+    c->tb_stage_bytes = stage_bytes;
+  }
+  if (!c->trk_copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->trk_copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->trk_copy_event, hipEventDisableTiming));
+  }
+  return SE3TN_OK;
+}
+
+int se3tn_on_track_batch(se3tn_ctx* c, se3tn_mesh* m, int n, const double* prev_poses, const double K[9], double object_width_mm,
+                         const uint8_t* const* rgb, const uint16_t* const* depth, int H, int W, uint8_t* rgbA_dev, uint16_t* depthA_dev,
+                         double* pose_out, float* trans_out, float* rot_out, int32_t* bbox_vu, void* stream) {
+  if (!c || c->device < 0 || !m || !prev_poses || !K || !rgb || !depth || H < 1 || W < 1 || !pose_out || !(object_width_mm > 0))
+    return fail(SE3TN_E_ARG, "se3tn_on_track_batch: bad argument");
+  if (n < 1 || n > c->max_batch) return fail(SE3TN_E_ARG, "se3tn_on_track_batch: n outside [1, max_batch]");
+  if (!c->have_norm) return fail(SE3TN_E_STATE, "se3tn_on_track_batch: call se3tn_set_normalization first");
+  if (stream_is_capturing((hipStream_t)stream)) return fail(SE3TN_E_STATE, "se3tn_on_track_batch: synchronous call, not capturable");
+  hipStream_t st = (hipStream_t)stream;
+  // pass 1 (host float64): the windows of every pair (predict.py:231-235 / :201-206) and the size of the staged sub-images
+  std::vector<int32_t> win(8 * (size_t)n), vu(8 * (size_t)n);
+  std::vector<size_t> off_rgb(n), off_d(n);
+  std::vector<int> geo(4 * (size_t)n);        // x0, y0, sw, sh of the staged sub-image
+  size_t bytes = (((size_t)n * 128) + 255) & ~(size_t)255;   // the poses in front
+  for (int i = 0; i < n; ++i) {
+    const double* P = prev_poses + 16 * (size_t)i;
+    int32_t* wB = &win[8 * (size_t)i];
+    int32_t* wA = wB + 4;
+    if (!rgb[i] || !depth[i]) return fail(SE3TN_E_ARG, "se3tn_on_track_batch: null frame pointer");
+    if (!(P[11] > 0) || !bbox_window(P, K, object_width_mm, 1000.0, wB, &vu[8 * (size_t)i]) || !bbox_window(P, K, object_width_mm, -1000.0, wA, nullptr))
+      return fail(SE3TN_E_ARG, "se3tn_on_track_batch: a pose is not in front of the camera (z <= 0 or not finite)");
+    if (wB[2] <= wB[0] || wB[3] <= wB[1]) return fail(SE3TN_E_ARG, "se3tn_on_track_batch: empty crop window");
+    int x0 = wB[0] > 0 ? wB[0] : 0, x1 = wB[2] < W ? wB[2] : W;
+    int y0 = wB[1] > 0 ? wB[1] : 0, y1 = wB[3] < H ? wB[3] : H;
+    int sw = x1 - x0, sh = y1 - y0;
+    if (sw <= 0 || sh <= 0) { sw = sh = -1; x0 = wB[0] - 8; y0 = wB[1] - 8; }   // the window misses the frame: a 1 x 1 zero sub-image
+    geo[4 * i] = x0; geo[4 * i + 1] = y0; geo[4 * i + 2] = sw; geo[4 * i + 3] = sh;
+    const size_t px = sw > 0 ? (size_t)sw * sh : 1;
+    off_rgb[i] = bytes; bytes += (px * 3 + 63) & ~(size_t)63;
+    off_d[i] = bytes;   bytes += (px * 2 + 63) & ~(size_t)63;
+  }
+  if (int rc = reserve_track_batch(c, m, n, bytes)) return rc;
+  // image A of all n poses: the instance table goes up on the launch stream, then FOUR launches (grid.y = pose)
+  uint8_t* rA = rgbA_dev ? rgbA_dev : c->tb_rgbA;
+  uint16_t* dA = depthA_dev ? depthA_dev : c->tb_depthA;
+  RasterArgs ra{};
+  raster_common(ra, c, m, rA, dA);
+  ra.rw = RES; ra.rh = RES; ra.mode = 0;
+  ra.vpost = m->b_vpost; ra.vsnap = m->b_vsnap; ra.big = m->b_big; ra.clipq = m->b_clipq; ra.zbuf = c->tb_zbuf;
+  for (int i = 0; i < n; ++i) {
+    RasterArgs one{};
+    if (!vispy_uniforms(one, prev_poses + 16 * (size_t)i, K, &win[8 * (size_t)i + 4])) return fail(SE3TN_E_ARG, "se3tn_on_track_batch: singular pose");
+    RasterInstance& I = c->tb_inst_host[i];
+    std::memcpy(I.PV, one.PV, sizeof(I.PV));
+    std::memcpy(I.light, one.light, sizeof(I.light));
+    I._pad = 0.f; I.dA = one.dA; I.dB = one.dB;
+  }
+  HIPCHK(hipMemcpyAsync(c->tb_inst_dev, c->tb_inst_host, sizeof(RasterInstance) * n, hipMemcpyHostToDevice, st));
+  ra.inst = c->tb_inst_dev;
+  HIPCHK(launch_raster(ra, st, n));
+  // the frames' windows: staged through pinned memory while the rasteriser runs, ONE copy with the poses in front
+  uint8_t* hp = c->tb_stage_host;
+  std::memcpy(hp, prev_poses, (size_t)n * 128);
+  for (int i = 0; i < n; ++i) {
+    const int x0 = geo[4 * i], y0 = geo[4 * i + 1], sw = geo[4 * i + 2], sh = geo[4 * i + 3];
+    if (sw < 0) { std::memset(hp + off_rgb[i], 0, 3); std::memset(hp + off_d[i], 0, 2); continue; }
+    for (int y = 0; y < sh; ++y) {
+      std::memcpy(hp + off_rgb[i] + (size_t)y * sw * 3, rgb[i] + ((size_t)(y0 + y) * W + x0) * 3, (size_t)sw * 3);
+      std::memcpy(hp + off_d[i] + (size_t)y * sw * 2, depth[i] + (size_t)(y0 + y) * W + x0, (size_t)sw * 2);
+    }
+  }
+  HIPCHK(hipMemcpyAsync(c->tb_stage_dev, hp, bytes, hipMemcpyHostToDevice, c->trk_copy_stream));
+  HIPCHK(hipEventRecord(c->trk_copy_event, c->trk_copy_stream));
+  HIPCHK(hipStreamWaitEvent(st, c->trk_copy_event, 0));
+  // both crops of every pair (data_augmentation.py:124-189 with poseA's z), 64 descriptors per launch
+  std::vector<se3tn_crop> crops(2 * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const double z_mm = prev_poses[16 * (size_t)i + 11] * 1000;
+    se3tn_crop& ca = crops[i];
+    ca.rgb = rA + (size_t)i * RES * RES * 3; ca.depth = dA + (size_t)i * RES * RES; ca.H = RES; ca.W = RES;
+    ca.left = 0; ca.top = 0; ca.right = RES; ca.bottom = RES; ca.z_offset_mm = z_mm; ca.stats = 0; ca._pad = 0;
+    se3tn_crop& cb = crops[(size_t)n + i];
+    const int x0 = geo[4 * i], y0 = geo[4 * i + 1], sw = geo[4 * i + 2], sh = geo[4 * i + 3];
+    const int32_t* wB = &win[8 * (size_t)i];
+    cb.rgb = c->tb_stage_dev + off_rgb[i]; cb.depth = (const uint16_t*)(c->tb_stage_dev + off_d[i]);
+    cb.H = sw < 0 ? 1 : sh; cb.W = sw < 0 ? 1 : sw;
+    cb.left = wB[0] - x0; cb.top = wB[1] - y0; cb.right = wB[2] - x0; cb.bottom = wB[3] - y0;
+    cb.z_offset_mm = z_mm; cb.stats = 1; cb._pad = 0;
+  }
+  int rc = se3tn_preprocess(c, crops.data(), n, c->inA, stream);
+  if (rc == SE3TN_OK) rc = se3tn_preprocess(c, crops.data() + n, n, c->inB, stream);
+  float* trans_d = (float*)(c->tb_out_dev + (size_t)n * 128);
+  float* rot_d = trans_d + 3 * (size_t)n;
+  if (rc == SE3TN_OK)
+    rc = se3tn_infer(c, c->inA, c->inB, n, SE3TN_NHWC, trans_d, rot_d, (const double*)c->tb_stage_dev, (double*)c->tb_out_dev, stream);
+  if (rc != SE3TN_OK) { (void)hipStreamSynchronize(c->trk_copy_stream); return rc; }
+  HIPCHK(hipMemcpyAsync(c->tb_out_host, c->tb_out_dev, (size_t)n * 152, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::memcpy(pose_out, c->tb_out_host, (size_t)n * 128);
+  if (trans_out) std::memcpy(trans_out, c->tb_out_host + (size_t)n * 128, (size_t)n * 12);
+  if (rot_out) std::memcpy(rot_out, c->tb_out_host + (size_t)n * 140, (size_t)n * 12);
+  if (bbox_vu) std::memcpy(bbox_vu, vu.data(), sizeof(int32_t) * 8 * (size_t)n);
   return SE3TN_OK;
 }
 

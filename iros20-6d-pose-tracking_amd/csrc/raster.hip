@@ -39,7 +39,28 @@ namespace se3tn {
 constexpr int RASTER_BIG_PX = 256;   // bounding boxes above this many pixels go to the wave-per-triangle path of raster_queue_kernel
 constexpr int CLIP_RIGHT = 1, CLIP_TOP = 2, CLIP_FAR = 4, CLIP_LEFT = 8, CLIP_BOTTOM = 16, CLIP_NEAR = 32;
 
-__global__ __launch_bounds__(256) void raster_vertex_kernel(const RasterArgs a) {
+// batched launch: this workgroup's instance (blockIdx.y) -- uniforms from the instance table, scratch and outputs at its offset
+__device__ __forceinline__ RasterArgs raster_instance(const RasterArgs& a0) {
+  RasterArgs a = a0;
+  if (a0.inst != nullptr) {
+    const size_t b = blockIdx.y;
+    const RasterInstance* __restrict__ I = a0.inst + b;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a.PV[k] = I->PV[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.light[k] = I->light[k];
+    a.dA = I->dA; a.dB = I->dB;
+    const size_t px = (size_t)a0.rw * a0.rh;
+    a.vpost += b * a0.V; a.vsnap += b * a0.V;
+    a.zbuf += b * px;
+    a.big += b * (size_t)(1 + a0.F); a.clipq += b * (size_t)(1 + a0.F);
+    a.rgb += b * px * 3; a.depth += b * px;
+  }
+  return a;
+}
+
+__global__ __launch_bounds__(256) void raster_vertex_kernel(const RasterArgs a0) {
+  const RasterArgs a = raster_instance(a0);
   const int i = blockIdx.x * 256 + threadIdx.x;
   // this launch also clears the z-buffer and the two queue counters (they are first touched by the NEXT launch)
   for (int p = i; p < a.rw * a.rh; p += gridDim.x * 256) a.zbuf[p] = ~0ull;
@@ -208,7 +229,8 @@ __device__ __forceinline__ int tri_load(const RasterArgs& a, int t, float4 post[
   return (f0 | f1 | f2) ? 2 : 1;
 }
 
-__global__ __launch_bounds__(256) void raster_triangle_kernel(const RasterArgs a) {
+__global__ __launch_bounds__(256) void raster_triangle_kernel(const RasterArgs a0) {
+  const RasterArgs a = raster_instance(a0);
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= a.F) return;
   float4 post[3];
@@ -293,7 +315,8 @@ constexpr int CLIP_MAX_ROWS = 2048;   // frame heights the outline tables hold (
 // one wave (the first of a clip block of raster_queue_kernel) per queued triangle: lane 0 clips the triangle to a polygon and snaps it, the wave
 // walks the polygon's edges IN ORDER (a later edge overwrites an earlier one on a shared row, as the span tables of the
 // implementation do), then rasterises the rows of the outline
-__global__ __launch_bounds__(256) void raster_queue_kernel(const RasterArgs a) {
+__global__ __launch_bounds__(256) void raster_queue_kernel(const RasterArgs a0) {
+  const RasterArgs a = raster_instance(a0);
   __shared__ int tab[2][CLIP_MAX_ROWS];   // [0] left, [1] right
   __shared__ int PX[12], PY[12], pn;
   if (blockIdx.x < BIG_BLOCKS) {
@@ -435,7 +458,8 @@ __device__ __forceinline__ float interp(const TriSetup& s, const Interp& it, flo
   return plane_eval(A, B, C, it.xx, it.yy) * it.rcp;
 }
 
-__global__ __launch_bounds__(256) void raster_resolve_kernel(const RasterArgs a) {
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const RasterArgs a0) {
+  const RasterArgs a = raster_instance(a0);
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= a.rw * a.rh) return;
   // GL window row j counts bottom-up, and glReadPixels returns rows in that order.  Mode 0: the reference reshapes the buffer
@@ -531,14 +555,16 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const RasterArgs a)
   }
 }
 
-hipError_t launch_raster(const RasterArgs& a, hipStream_t st) {
+hipError_t launch_raster(const RasterArgs& a, hipStream_t st, int instances) {
   // one thread per vertex; the z-buffer clear strides over the grid (at least 128 blocks, or one per 256 pixels if that is fewer)
+  // instances > 1 (a.inst set): grid.y = instance, the same four launches for all poses
   const int vb = (a.V + 255) / 256, zb = (a.rw * a.rh + 255) / 256;
   const int clear_blocks = zb < 128 ? zb : 128;
-  hipLaunchKernelGGL(raster_vertex_kernel, dim3(vb > clear_blocks ? vb : clear_blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(raster_triangle_kernel, dim3((a.F + 255) / 256), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(raster_queue_kernel, dim3(BIG_BLOCKS + CLIP_BLOCKS), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(raster_resolve_kernel, dim3((a.rw * a.rh + 255) / 256), dim3(256), 0, st, a);
+  const unsigned ny = a.inst ? (unsigned)instances : 1u;
+  hipLaunchKernelGGL(raster_vertex_kernel, dim3(vb > clear_blocks ? vb : clear_blocks, ny), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(raster_triangle_kernel, dim3((a.F + 255) / 256, ny), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(raster_queue_kernel, dim3(BIG_BLOCKS + CLIP_BLOCKS, ny), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(raster_resolve_kernel, dim3((a.rw * a.rh + 255) / 256, ny), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -261,7 +261,7 @@ hipError_t launch_wino_block(const WinoArgs& c1, const float* U2, const float* u
                              float* keep_out2, const TailArgs* tl, hipStream_t st, int mark_after_mid(void*), void* mark_ctx);
 // stem + max-pool of both branches in one launch at batch 1-2 (stem_pool_small.hip)
 #ifndef SE3TN_STEM_SMALL_MAX_N
-#define SE3TN_STEM_SMALL_MAX_N 2
+#define SE3TN_STEM_SMALL_MAX_N 5
 #endif
 hipError_t launch_stem_pool_small(const float* inA, const float* inB, const float* w, const float* bias, float* pool, int n, hipStream_t st);
 // the 64 -> 64 trunk convs at batch 1-5 without a K split (conv64_small.hip)
@@ -280,7 +280,16 @@ hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h,
 
 // rasteriser (raster.hip)
 constexpr double R_NEAR_D = 0.1, R_FAR_D = 2.0;   // vispy_renderer.py:139-140, offscreen_renderer.py znear / zfar
+// per-instance uniforms of a BATCHED rasteriser launch (grid.y = instance: n poses of one mesh in four launches, se3tn_on_track_batch)
+struct RasterInstance {
+  float PV[16];
+  float light[3];
+  float _pad;
+  double dA, dB;
+};
 struct RasterArgs {
+  const RasterInstance* inst;  // nullptr: one instance, uniforms below.  Otherwise instance b = blockIdx.y takes PV / light / dA / dB from
+                               // inst[b] and its scratch / outputs at b x (V | 1 + F | rw rh) elements behind the pointers below
   const float* verts;    // [V,3] object space
   const float* normals;  // [V,3]
   const float* colors;   // [V,3] in [0,1]
@@ -306,7 +315,7 @@ struct RasterArgs {
   unsigned tex_off[16];  // byte offset of every mip level
   float kd[3];           // base colour factor (mtl Kd)
 };
-hipError_t launch_raster(const RasterArgs& a, hipStream_t st);
+hipError_t launch_raster(const RasterArgs& a, hipStream_t st, int instances = 1);
 
 // depth hole filling (depth_fill.hip)
 struct FillDepthArgs {

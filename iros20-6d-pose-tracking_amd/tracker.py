@@ -98,6 +98,7 @@ class Tracker:
         self.prev_depth = None
         self.frame_cnt = 0
         self._one_call_state = None
+        self._batch_state = None
         self.one_call = True     # on_track through se3tn_on_track when the built-in rasteriser renders image A (False: step by step)
         self.errs = []
         dev = "cuda:%d" % device
@@ -239,11 +240,61 @@ class Tracker:
     def on_track_batch(self, prev_poses, rgbs, depths):
         """Extension: n independent (pose, frame) pairs of the SAME object in one engine call -- several
         sequences / cameras / hypotheses (frames of one track are serial, so this is where batch > 1
-        comes from).  Same arithmetic per pair as on_track; returns [n,4,4] float64."""
+        comes from).  Same arithmetic per pair as on_track; returns [n,4,4] float64.
+        With the built-in rasteriser the whole step is ONE library call (se3tn_on_track_batch: image A of all n poses in four
+        launches, the frames' crop windows staged through pinned memory in one copy, no per-pair Python)."""
         from .renderer import HipRenderer
         n = len(prev_poses)
         if n > self.engine.max_batch:
             raise ValueError("on_track_batch: %d pairs > max_samples=%d given to Tracker()" % (n, self.engine.max_batch))
+        if self.one_call and isinstance(self.renderer, HipRenderer) and not self.renderer.full_frame and n > 0:
+            return self._on_track_batch_one_call(prev_poses, rgbs, depths)
+        return self._on_track_batch_stepwise(prev_poses, rgbs, depths)
+
+    def _on_track_batch_one_call(self, prev_poses, rgbs, depths):
+        import ctypes as C
+        from ._lib import check
+        from .engine import _stream_ptr
+        n = len(prev_poses)
+        poses = np.ascontiguousarray(np.stack([np.asarray(p, np.float64) for p in prev_poses]).reshape(n, 16))
+        frames_rgb, frames_dep = [], []
+        for i in range(n):
+            rgb = rgbs[i]
+            if not (type(rgb) is np.ndarray and rgb.dtype == np.uint8 and rgb.flags.c_contiguous):
+                rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+            if rgb.ndim != 3 or rgb.shape[2] != 3:
+                raise ValueError("rgb must be HxWx3 uint8")
+            dep = depths[i]
+            if not (type(dep) is np.ndarray and dep.dtype == np.uint16 and dep.flags.c_contiguous and dep.shape == rgb.shape[:2]):
+                dep = _depth_u16(dep, rgb)
+            if rgb.shape != frames_rgb[0].shape if frames_rgb else False:
+                raise ValueError("on_track_batch: the frames of one call must have one size")
+            frames_rgb.append(rgb); frames_dep.append(dep)
+        H, W = int(frames_rgb[0].shape[0]), int(frames_rgb[0].shape[1])
+        st = self._batch_state
+        if st is None or st["n"] < n:
+            dev = self._dev
+            st = self._batch_state = dict(
+                n=n, rgbA=torch.empty((n, 176, 176, 3), dtype=torch.uint8, device=dev),
+                depthA=torch.empty((n, 176, 176), dtype=torch.int16, device=dev),
+                K=np.ascontiguousarray(self.K, np.float64))
+        out = np.empty((n, 16), np.float64)
+        tr, ro, bb = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.empty((n, 4, 2), np.int32)
+        prgb = (C.c_void_p * n)(*[f.ctypes.data for f in frames_rgb])
+        pdep = (C.c_void_p * n)(*[f.ctypes.data for f in frames_dep])
+        check(self.engine.lib.se3tn_on_track_batch(
+            self.engine._h, self.renderer._m, n, C.c_void_p(poses.ctypes.data), st["K"].ctypes.data_as(C.POINTER(C.c_double)),
+            C.c_double(float(self.object_width)), prgb, pdep, H, W, C.c_void_p(st["rgbA"].data_ptr()), C.c_void_p(st["depthA"].data_ptr()),
+            C.c_void_p(out.ctypes.data), C.c_void_p(tr.ctypes.data), C.c_void_p(ro.ctypes.data), C.c_void_p(bb.ctypes.data), _stream_ptr()),
+            "se3tn_on_track_batch")
+        self.last_prediction = dict(trans=tr, rot=ro, bbox=bb, rgbA=list(st["rgbA"][:n]), depthA=list(st["depthA"][:n]))
+        self.frame_cnt += 1
+        return out.reshape(n, 4, 4)
+
+    def _on_track_batch_stepwise(self, prev_poses, rgbs, depths):
+        """on_track_batch step by step (injected renderers, the pyrender route, one_call = False): per pair a render and two uploads"""
+        from .renderer import HipRenderer
+        n = len(prev_poses)
         dev = self._dev
         cropsA, cropsB, keep, bboxes = [], [], [], []
         poses = np.stack([np.asarray(p, np.float64) for p in prev_poses])

@@ -293,6 +293,48 @@ def run_regime_batch(se3, regime, tracks, frames=50, subdiv=4, winograd=None, co
     return out
 
 
+def time_batch(se3, tracks, frames=120, warmup=10, subdiv=5, regime="ycb_video_5deg", check_frames=3):
+    """Throughput of ``Tracker.on_track_batch`` as a deployment calls it: `tracks` independent closed-loop tracks
+    advanced by ONE call per step -- host float64 bboxes, image A of every pose rendered on the device, the camera frames' crop windows
+    staged from HOST memory and uploaded (PCIe-inclusive), both crops, the network on `tracks` pairs, the pose update, the poses read
+    back; wall clock around the call.  The same configuration is then checked pair by pair against the oracle for `check_frames`
+    steps (run_regime_batch)."""
+    seq = _frames()
+    trk, sd, (mean, std), nfaces = make_tracker(se3, subdiv, None, regime, seq, max_samples=tracks)
+    n = tracks
+    phase = [37 * k for k in range(n)]
+    foff = [5 * k for k in range(n)]
+    P = []
+    for k in range(n):
+        Pk = Fx.pose(3 + k, (0.0, 0.0, 0.8))
+        Pk[:3, 3] = anchor(phase[k])
+        P.append(Pk)
+    lat = []
+    for f in range(warmup + frames):
+        rgbs = [seq[(f + foff[k]) % N_DISTINCT_FRAMES][0] for k in range(n)]
+        deps = [seq[(f + foff[k]) % N_DISTINCT_FRAMES][1] for k in range(n)]
+        t0 = time.perf_counter()
+        Q = trk.on_track_batch(P, rgbs, deps)
+        if f >= warmup:
+            lat.append(time.perf_counter() - t0)
+        for k in range(n):
+            N = Q[k].copy()
+            N[:3, 3] = anchor(f + 1 + phase[k]) + (Q[k][:3, 3] - P[k][:3, 3])
+            if _lost(N):
+                N[:3, 3] = anchor(f + 1 + phase[k])
+            P[k] = N
+    lat = np.array(lat) * 1e3
+    out = {"tracks": n, "steps": frames, "ms_per_step_median": round(float(np.median(lat)), 4), "ms_per_step_p95": round(float(np.percentile(lat, 95)), 4),
+           "pairs_per_s": round(n * 1000.0 / float(np.median(lat)), 1), "faces": nfaces,
+           "one_library_call_per_step": bool(getattr(trk, "one_call", False))}
+    del trk
+    if check_frames > 0:
+        r = run_regime_batch(se3, regime, n, frames=check_frames, subdiv=subdiv)
+        out["parity"] = {k: r[k] for k in ("pairs_checked", "imageA_rendered_by_oracle", "imageA_identical", "bbox_mismatches", "max_abs_logit_diff",
+                                           "max_abs_trans_rot", "max_abs_pose", "ok")}
+    return out
+
+
 def golden_replay(se3):
     """Image A of the HIP rasteriser against the COMMITTED outputs of the reference's own renderer (the unmodified VispyRenderer /
     predict.Tracker on the goldens' GL implementation): tests/golden/gl_swiftshader*.npz (6 poses / meshes, both NumPy generations of

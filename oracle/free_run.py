@@ -129,7 +129,7 @@ class SynthTrackProblem:
 
     def __init__(self, seed, sequence, weights=None):
         from . import synth_track as ST
-        self.seed, self.regime = seed, "ycb_video_5deg"
+        self.seed, self.regime = seed, ST.REGIME
         self.mesh = ST.make_object()
         self.K = camera_matrix()
         self.tn, self.rn = ST.TRANS_NORMALIZER, ST.ROT_NORMALIZER
@@ -385,29 +385,41 @@ def camera_matrix():
     return np.array([[c["focalX"], 0, c["centerX"]], [0, c["focalY"], c["centerY"]], [0, 0, 1.0]])
 
 
-def _run_pairs(se3, problems, frames, nw, threads, control_keys, metrics):
-    """problems: {key: Problem}.  Runs the HIP track of every problem, the oracle track (and, for control_keys, the channels-last
-    control track) in worker processes; returns {key: (hip, oracle, control | None)}."""
-    tmp = tempfile.mkdtemp(prefix="se3tn_free_")
-    futures, hip = {}, {}
-    pool = _pool(nw)
-    try:
+class PairRunner:
+    """One worker pool + scratch directory shared by every problem set of a report: the HIP tracks run in this process as the
+    problems are submitted, the oracle / control tracks in the pool; `collect` waits for them."""
+
+    def __init__(self, se3, workers, threads):
+        self.se3, self.threads = se3, threads
+        self.tmp = tempfile.mkdtemp(prefix="se3tn_free_")
+        self.pool = _pool(workers)
+        self.n = 0
+
+    def submit(self, problems, frames, control_keys):
+        hip, futures = {}, {}
         for key, pb in problems.items():
-            trk = make_hip_tracker(se3, pb)
-            path = os.path.join(tmp, "t%d" % len(hip))
+            trk = make_hip_tracker(self.se3, pb)
+            path = os.path.join(self.tmp, "t%d" % self.n)
+            self.n += 1
             hip[key] = hip_track(trk, pb, frames, path)
-            job = dict(problem=pb.spec(), frames=frames, numpy_rule=trk.engine.get_offset_rule(), threads=threads, images=path)
-            futures[(key, "oracle")] = pool.submit(oracle_track, job)
+            job = dict(problem=pb.spec(), frames=frames, numpy_rule=trk.engine.get_offset_rule(), threads=self.threads, images=path)
+            futures[(key, "oracle")] = self.pool.submit(oracle_track, job)
             if key in control_keys:
-                futures[(key, "control")] = pool.submit(oracle_track, dict(job, variant="channels_last"))
+                futures[(key, "control")] = self.pool.submit(oracle_track, dict(job, variant="channels_last"))
             del trk
-        res = {(key, kind): fut.result() for (key, kind), fut in futures.items()}
-    finally:
-        pool.shutdown(wait=True, cancel_futures=True)
-        for fn in os.listdir(tmp):
-            os.unlink(os.path.join(tmp, fn))
-        os.rmdir(tmp)
-    return {key: (hip[key], res[(key, "oracle")], res.get((key, "control"))) for key in problems}
+        return hip, futures
+
+    @staticmethod
+    def collect(handle):
+        hip, futures = handle
+        res = {k: fut.result() for k, fut in futures.items()}
+        return {key: (hip[key], res[(key, "oracle")], res.get((key, "control"))) for key in hip}
+
+    def close(self):
+        self.pool.shutdown(wait=True, cancel_futures=True)
+        for fn in os.listdir(self.tmp):
+            os.unlink(os.path.join(self.tmp, fn))
+        os.rmdir(self.tmp)
 
 
 def _blocks(tracks, pts, metrics, label=lambda key: "seed_%d" % key):
@@ -430,7 +442,8 @@ def _blocks(tracks, pts, metrics, label=lambda key: "seed_%d" % key):
     return blk
 
 
-def run_free(se3, frames=1000, seeds=(0, 1, 2), regimes=None, subdiv=5, workers=None, metrics=None, control_seeds=(0,)):
+def run_free(se3, frames=1000, seeds=(0, 1, 2), regimes=None, subdiv=5, workers=None, metrics=None, control_seeds=(0,), runner=None,
+             defer=False):
     """The `free_running` block on the RANDOM-INIT stand-in: for every regime and seed, the HIP tracker's own closed loop and the
     oracle's own closed loop over the same `frames` camera frames from the same start; for `control_seeds` also the CONTROL: the
     oracle's closed loop with channels-last network inputs (same reference arithmetic, another summation order) -- how far the
@@ -449,7 +462,22 @@ def run_free(se3, frames=1000, seeds=(0, 1, 2), regimes=None, subdiv=5, workers=
         sd = calibrated_weights(seed, mesh, CL._frames(), K)
         for regime in regimes:
             problems[(regime, seed)] = RandomInitProblem(seed, regime, sd=sd, mesh=mesh)
-    tracks = _run_pairs(se3, problems, frames, nw, threads, {(r, s) for r in regimes for s in control_seeds}, metrics)
+    own = runner is None
+    assert not (defer and own), "defer needs the caller's runner"
+    runner = runner or PairRunner(se3, nw, threads)
+    try:
+        handle = runner.submit(problems, frames, {(r, s) for r in regimes for s in control_seeds})
+        if defer:                                            # the caller collects later (other problem sets share the pool)
+            return lambda: _finish_free(runner.collect(handle), frames, seeds, control_seeds, regimes, pts, metrics, runner, t_start)
+        tracks = runner.collect(handle)
+    finally:
+        if own:
+            runner.close()
+    return _finish_free(tracks, frames, seeds, control_seeds, regimes, pts, metrics, runner, t_start)
+
+
+def _finish_free(tracks, frames, seeds, control_seeds, regimes, pts, metrics, runner, t_start):
+    nw, threads = runner.pool._max_workers, runner.threads
     out = {"what": "two INDEPENDENT closed loops per (regime, seed) over the same frames from the same start: the HIP tracker feeds back "
                    "its own pose and renders its own image A, the CPU oracle feeds back ITS own pose and renders its own image A "
                    "(oracle/free_run.py).  `control`: the oracle against ITSELF with channels-last network inputs (the same torch-CPU "
@@ -473,7 +501,8 @@ def against_ground_truth(track, pb, pts, metrics):
             "adds_mm_median": float(np.median(adi) * 1e3), "adds_mm_max": float(adi.max() * 1e3), "reinits": int(track["reinits"])}
 
 
-def run_tracked(se3, frames=1000, seeds=(0, 1, 2), workers=None, metrics=None, control_seeds=(0,), weights=None):
+def run_tracked(se3, frames=1000, seeds=(0, 1, 2), workers=None, metrics=None, control_seeds=(0,), weights=None, runner=None,
+                defer=False):
     """The `free_running` block on the synthetic tracking problem WITH ground truth and trained stand-in weights
     (oracle/synth_track.py, tests/golden/synth_tracker.npz): the loop of predict.py:416-420 unmodified on both sides -- started at
     the ground-truth pose of frame 0, prev_pose <- on_track(prev_pose, frame) -- plus what configs[2] reports: ADD / ADD-S AUC of each
@@ -486,23 +515,46 @@ def run_tracked(se3, frames=1000, seeds=(0, 1, 2), workers=None, metrics=None, c
     t_start = time.time()
     tmp = tempfile.mkdtemp(prefix="se3tn_seq_")
     problems = {}
+    own = runner is None
+    runner = runner or PairRunner(se3, nw, threads)
+    nw, threads = runner.pool._max_workers, runner.threads
     try:
-        with _pool(nw * threads) as pool:                   # the object patches of every frame (CPU renders), in parallel
-            for seed in seeds:
-                seq = ST.make_sequence(seed, frames + 1, K, pool)
-                path = os.path.join(tmp, "seq_%d.npz" % seed)
-                seq.save(path)
-                problems[seed] = SynthTrackProblem(seed, path, weights)
+        for seed in seeds:                                  # the object patches of every frame (CPU renders), in the pool
+            seq = ST.make_sequence(seed, frames + 1, K, runner.pool)
+            path = os.path.join(tmp, "seq_%d.npz" % seed)
+            seq.save(path)
+            problems[seed] = SynthTrackProblem(seed, path, weights)
         t_seq = time.time() - t_start
-        tracks = _run_pairs(se3, problems, frames, nw, threads, set(control_seeds), metrics)
-    finally:
+        handle = runner.submit(problems, frames, set(control_seeds))
+    except BaseException:
+        if own:
+            runner.close()
+        _rmtree(tmp)
+        raise
+
+    def finish():
+        try:
+            tracks = runner.collect(handle)
+        finally:
+            if own:
+                runner.close()
+            _rmtree(tmp)
+        return _finish_tracked(tracks, problems, frames, seeds, control_seeds, se3, metrics, nw, threads, t_seq, t_start)
+    return finish if defer else finish()
+
+
+def _rmtree(tmp):
+    if os.path.isdir(tmp):
         for fn in os.listdir(tmp):
             os.unlink(os.path.join(tmp, fn))
         os.rmdir(tmp)
+
+
+def _finish_tracked(tracks, problems, frames, seeds, control_seeds, se3, metrics, nw, threads, t_seq, t_start):
     pb0 = problems[seeds[0]]
     pts = model_points_of(pb0.mesh, se3)
     out = {"what": "synthetic tracking problem with ground truth (oracle/synth_track.py): an ellipsoid with a smooth colour pattern moves "
-                   "4-7 mm and 1-2.5 degrees per frame in front of structured backgrounds; stand-in weights TRAINED on that problem "
+                   "4-7 mm and 3-8 degrees per frame in front of structured backgrounds; stand-in weights TRAINED on that problem "
                    "(tests/golden/synth_tracker.npz: the pretrained YCB weights are not available offline); the loop of predict.py:"
                    "416-420 unmodified: start at the ground-truth pose of frame 0, prev_pose <- on_track(prev_pose, frame).  Two "
                    "INDEPENDENT runs of that loop -- HIP tracker / CPU oracle -- and the oracle against itself (channels-last control)",
@@ -521,4 +573,28 @@ def run_tracked(se3, frames=1000, seeds=(0, 1, 2), workers=None, metrics=None, c
     out["against_ground_truth"] = gt
     out["hz_hip"] = round(1000.0 / float(np.median([h["ms_per_frame"] for h, _, _ in tracks.values()])), 1)
     out["seconds"] = round(time.time() - t_start, 1)
+    return out
+
+
+def run_report(se3, frames_tracked=1000, frames_random=1000, seeds=(0, 1, 2), control_seeds=(0,), workers=None):
+    """Both problem sets through ONE worker pool (bench.py's `track.free_running`): the synthetic tracking problem first (its
+    sequences are rendered in the still-idle pool), then the random-init stand-in; both sets of oracle tracks run side by side."""
+    have_weights = os.path.exists(default_synth_weights())
+    njobs = (len(seeds) + len(control_seeds)) * (2 * (frames_random > 0) + (frames_tracked > 0 and have_weights))
+    nw, threads = (workers, 2) if workers else default_workers(max(njobs, 1))
+    runner = PairRunner(se3, nw, threads)
+    out, fin_t, fin_r = {}, None, None
+    try:
+        if frames_tracked > 0 and have_weights:
+            fin_t = run_tracked(se3, frames_tracked, seeds, control_seeds=control_seeds, runner=runner, defer=True)
+        elif frames_tracked > 0:
+            out["synthetic_tracking_trained_weights"] = {"skipped": "tests/golden/synth_tracker.npz not found"}
+        if frames_random > 0:
+            fin_r = run_free(se3, frames_random, seeds, control_seeds=control_seeds, runner=runner, defer=True)
+        if fin_t is not None:
+            out["synthetic_tracking_trained_weights"] = fin_t()
+        if fin_r is not None:
+            out["random_init"] = fin_r()
+    finally:
+        runner.close()
     return out

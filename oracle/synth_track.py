@@ -5,7 +5,7 @@ neither is available offline).  TEST INFRASTRUCTURE ONLY: fixtures + the data th
   object      an ellipsoid (semi-axes 60 / 45 / 35 mm) with a smooth vertex-colour pattern: rotation and translation are both
               observable in RGB-D, unlike the random-colour sphere of oracle/closed_loop.py
   trajectory  ground-truth pose G_f: translation on closed_loop.anchor (4-7 mm per frame), rotation a seeded smooth curve
-              (1-2.5 degrees per frame) -- inside the 0.03 m / 5 degree normalisers of predict.py:128
+              (3-8 degrees per frame) -- inside the 0.03 m / 30 degree normalisers of predict.py:586 (the YCBInEOAT regime)
   frame f     a structured 480x640 RGB-D background (fixtures.structured_frame, 16 distinct, cycled) with the object rendered
               at G_f pasted in: the reference's renderer (oracle/ss_fast.py) at the native resolution of the crop window
   sample      (image A rendered at a perturbed pose P_A, the frame cropped at P_A's window as predict.py:236-262 does, labels
@@ -22,7 +22,9 @@ from . import se3_oracle as O
 
 RADII = np.array([0.060, 0.045, 0.035])
 OBJECT_WIDTH_MM = CL.OBJECT_WIDTH_MM
-TRANS_NORMALIZER, ROT_NORMALIZER = CL.REGIMES["ycb_video_5deg"]
+REGIME = "ycbineoat_30deg"          # predict.py:586: 0.03 m, 30 degrees.  (Under the 5-degree normaliser of predict.py:128 the rotation head
+                                    # did not start to learn within the CPU budget of the fixture -- 900 steps of 32 pairs; translation did.)
+TRANS_NORMALIZER, ROT_NORMALIZER = CL.REGIMES[REGIME]
 N_BACKGROUNDS = CL.N_DISTINCT_FRAMES
 
 
@@ -50,8 +52,8 @@ def gt_pose(seed, f):
     rng = np.random.default_rng(7000 + seed)
     R0 = rodrigues64(rng.normal(0, 0.8, 3))
     ph = rng.uniform(0, 2 * np.pi, 3)
-    w = np.array([0.40 * np.sin(2 * np.pi * f / 173.0 + ph[0]), 0.30 * np.sin(2 * np.pi * f / 211.0 + ph[1]),
-                  0.45 * np.sin(2 * np.pi * f / 139.0 + ph[2])])
+    w = np.array([1.20 * np.sin(2 * np.pi * f / 173.0 + ph[0]), 0.90 * np.sin(2 * np.pi * f / 211.0 + ph[1]),
+                  1.35 * np.sin(2 * np.pi * f / 139.0 + ph[2])])
     P = np.eye(4)
     P[:3, :3] = rodrigues64(w) @ R0
     P[:3, 3] = CL.anchor(f + 37 * seed)

@@ -226,6 +226,39 @@ def test_on_track_batch_equals_sequential(se3):
         trk.on_track_batch(poses * 2, [f[0] for f in frames] * 2, [f[1] for f in frames] * 2)
 
 
+@pytest.mark.parametrize("n", [1, 3, 8, 21])
+def test_on_track_batch_one_call_equals_the_stepwise_path(se3, n):
+    """se3tn_on_track_batch (image A of all n poses in four batched rasteriser launches, windows staged in one copy, one library
+    call) against the step-by-step path of the same Tracker (a render + two uploads per pair): bit-identical image A, bbox, (trans,
+    rot) and pose for every pair -- windows inside the frame, crossing its border and missing it altogether, frames repeated."""
+    sd = O.make_state_dict(0, head_gain=0.01)
+    mean, std = Fx.mean_std(0)
+    mesh = Fx.icosphere(3, 0.05, 2)
+    trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=150.0), mean, std, {"state_dict": sd}, max_samples=n)
+    trk.renderer = se3.HipRenderer(trk.engine, mesh)
+    frames = [Fx.synthetic_frame(70 + i) for i in range(4)]
+    ts = [(0.0, 0.0, 0.8), (0.21, 0.0, 0.7), (-0.2, -0.17, 0.75), (0.0, 0.15, 0.5), (0.6, 0.5, 0.9)]    # the last: window off the frame
+    poses = [Fx.pose(3 + i, ts[i % len(ts)]) for i in range(n)]
+    rgbs, deps = [frames[i % 4][0] for i in range(n)], [frames[i % 4][1] for i in range(n)]
+    assert trk.one_call
+    got = trk.on_track_batch(poses, rgbs, deps)
+    lp = trk.last_prediction
+    g = dict(trans=lp["trans"].copy(), rot=lp["rot"].copy(), bbox=lp["bbox"].copy(),
+             rgbA=[t.cpu().numpy() for t in lp["rgbA"]], depthA=[t.cpu().numpy() for t in lp["depthA"]])
+    trk.one_call = False
+    want = trk.on_track_batch(poses, rgbs, deps)
+    lw = trk.last_prediction
+    assert got.shape == (n, 4, 4) and np.array_equal(got, want)
+    assert np.array_equal(g["trans"], lw["trans"]) and np.array_equal(g["rot"], lw["rot"]) and np.array_equal(g["bbox"], lw["bbox"])
+    for i in range(n):
+        assert np.array_equal(g["rgbA"][i], lw["rgbA"][i].cpu().numpy()) and np.array_equal(g["depthA"][i], lw["depthA"][i].cpu().numpy()), i
+        assert (g["depthA"][i] != 0).sum() > 500
+    # and per pair the single-frame call (batch-1 kernels: other summation order, same tolerance class as on_track's own batch test)
+    trk.one_call = True
+    one = np.stack([trk.on_track(poses[i], rgbs[i], deps[i]) for i in range(min(n, 5))])
+    assert np.abs(one - got[:len(one)]).max() < 1e-6
+
+
 def test_hipgraph_replay_matches_eager(se3):
     """se3tn_enable_graphs: the captured se3tn_infer replays bit-identically, tracks argument changes
     (new pointers -> new capture) and content changes (same buffers, new data)."""

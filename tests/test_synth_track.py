@@ -1,0 +1,88 @@
+"""The synthetic tracking problem with ground truth (oracle/synth_track.py): the stand-in for BASELINE configs[2] that HAS an
+object in the frames and weights trained on it.  CPU: the fixtures' own consistency (labels reproduce the ground truth through the
+reference's processPredict rule, per-frame motion inside the normalisers, the pasted object is where compute_bbox looks for it)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import closed_loop as CL, free_run as FR, se3_oracle as O, synth_track as ST
+
+
+def test_labels_reproduce_the_ground_truth_through_process_predict():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        G = ST.random_gt(rng)
+        A, trans, rot = ST.perturbed(G, rng)
+        B = O.process_predict(A, trans, rot, ST.TRANS_NORMALIZER, ST.ROT_NORMALIZER)       # datasets.py:159-175
+        assert np.abs(B - G).max() < 2e-7                                                  # (Rodrigues returns float32)
+        assert np.abs(trans).max() <= 0.9 and np.linalg.norm(rot) <= 0.9 + 1e-6
+
+
+def test_ground_truth_motion_per_frame_is_inside_the_normalisers():
+    from scipy.spatial.transform import Rotation
+    for seed in range(3):
+        P = [ST.gt_pose(seed, f) for f in range(400)]
+        dt = max(np.abs(P[f + 1][:3, 3] - P[f][:3, 3]).max() for f in range(399))
+        dr = max(np.linalg.norm(Rotation.from_matrix(P[f + 1][:3, :3] @ P[f][:3, :3].T).as_rotvec()) for f in range(399))
+        assert dt < 0.5 * ST.TRANS_NORMALIZER and dr < 0.75 * ST.ROT_NORMALIZER, (seed, dt, np.degrees(dr))
+        assert all(not CL._lost(p) for p in P)
+
+
+def test_object_is_pasted_where_the_crop_window_of_its_pose_is():
+    K = FR.camera_matrix()
+    om = CL.oracle_mesh(ST.make_object(3))
+    G = ST.gt_pose(1, 17)
+    patch = ST.object_patch(om, G, K)
+    l, t, r, b = ST.crop_window_of(G, K)
+    assert (patch[0], patch[1]) == (l, t) and patch[3].shape == (b - t, r - l) and patch[2].shape == (b - t, r - l, 3)
+    bg = ST.backgrounds()[0]
+    rgb, depth = ST.compose_frame(bg, patch)
+    changed = (depth != bg[1])
+    ys, xs = np.nonzero(changed)
+    assert changed.sum() > 2000 and l <= xs.min() and xs.max() < r and t <= ys.min() and ys.max() < b
+    # the object's silhouette is centred in its window (the window is centred on the projected object centre)
+    assert abs(xs.mean() - (l + r) / 2) < 6 and abs(ys.mean() - (t + b) / 2) < 6
+    # depth of the pasted pixels = the object's surface, within its extent of the pose's z
+    z = depth[changed].astype(np.float64)
+    assert np.abs(z - G[2, 3] * 1000).max() < 1000 * ST.RADII.max() + 2
+    # image A rendered at the SAME pose covers the same pixels as the crop of the frame (predict.py:193-262 alignment)
+    rgbA, depthA = CL.oracle_image_A(om, G, K, ST.OBJECT_WIDTH_MM)
+    bb = O.compute_bbox(G, K, ST.OBJECT_WIDTH_MM, scale=(1000, 1000, 1000))
+    rgbB, depthB = O.crop_bbox(rgb, np.where(changed, depth, 0).astype(np.uint16), bb, (176, 176))
+    inter = ((depthA > 0) & (depthB > 0)).sum()
+    union = ((depthA > 0) | (depthB > 0)).sum()
+    assert inter / union > 0.94, inter / union       # (edges: the crop is NEAREST-resampled from ~200 px, image A rendered at 176)
+
+
+def test_sequence_round_trips_through_its_file(tmp_path):
+    K = FR.camera_matrix()
+    seq = ST.make_sequence(2, 3, K, subdiv=2)
+    path = str(tmp_path / "s.npz")
+    seq.save(path)
+    back = ST.Sequence.load(path)
+    assert len(back) == 3 and back.seed == 2 and back.offset == seq.offset
+    for f in range(3):
+        a, b = seq.frame(f), back.frame(f)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[0].dtype == np.uint8 and a[1].dtype == np.uint16
+
+
+@pytest.mark.skipif(not os.path.exists(FR.default_synth_weights()), reason="tests/golden/synth_tracker.npz not generated")
+def test_trained_stand_in_contracts_on_the_oracle():
+    """the fixture's purpose: one oracle step from a PERTURBED pose lands closer to the ground truth than it started (contraction),
+    on frames the training never saw -- and the state_dict surface is the reference's (strict keys / shapes)"""
+    K = FR.camera_matrix()
+    sd, mean, std, info = FR.load_synth_weights(FR.default_synth_weights())
+    assert [k for k, _, _ in O.state_dict_spec()] == list(sd.keys()) and info["trained_tensors"] > 40
+    om = CL.oracle_mesh(ST.make_object())
+    rng = np.random.default_rng(5)
+    before, after = [], []
+    bgs = ST.backgrounds()
+    for i in range(6):
+        G = ST.gt_pose(3, 40 * i)
+        A, _, _ = ST.perturbed(G, rng, scale=0.6)
+        rgb, depth = ST.compose_frame(bgs[i], ST.object_patch(om, G, K))
+        rgbA, depthA = CL.oracle_image_A(om, A, K, ST.OBJECT_WIDTH_MM)
+        Q, _ = O.on_track(sd, A, rgb, depth, rgbA, depthA, K, ST.OBJECT_WIDTH_MM, mean, std, ST.TRANS_NORMALIZER, ST.ROT_NORMALIZER)
+        before.append(np.linalg.norm(A[:3, 3] - G[:3, 3])); after.append(np.linalg.norm(Q[:3, 3] - G[:3, 3]))
+    assert np.mean(after) < 0.5 * np.mean(before), (before, after)
