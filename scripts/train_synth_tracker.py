@@ -4,8 +4,8 @@ synthetic tracking problem of oracle/synth_track.py, so that the loop of predict
 reference's pretrained weights (which are not available offline).  TEST-FIXTURE GENERATOR, not product code; training itself is
 out of the hot path's scope.
 
-Only a SUBSET of the state_dict is trained (stems, the 64-channel blocks, convAB1, every BN affine, the two FC layers); every
-other tensor stays O.make_state_dict(BASE_SEED).  The fixture tests/golden/synth_tracker.npz holds the trained tensors rounded to
+Only a SUBSET of the state_dict is trained (stems, the 64-channel blocks, convAB1, convAB2, every BN affine, the two FC layers);
+every other tensor (the heads' 512-channel convs: 10.6 M of the 13.5 M parameters) stays O.make_state_dict(BASE_SEED).  The fixture tests/golden/synth_tracker.npz holds the trained tensors rounded to
 float16 (both sides load the same float32 values), the mean / std of the training set and the held-out errors.
 
     python scripts/train_synth_tracker.py --samples 6000 --steps 900 [--out tests/golden/synth_tracker.npz]"""
@@ -20,7 +20,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 BASE_SEED = 0
-TRAINABLE = r"^(convA1|convB1|convA2|convB2|convB3|convAB1)\.|\.(bn1|bn2|1)\.(weight|bias)$|^(trans_out|rot_out)\."
+TRAINABLE = r"^(convA1|convB1|convA2|convB2|convB3|convAB1|convAB2)\.|\.(bn1|bn2|1)\.(weight|bias)$|^(trans_out|rot_out)\."
 
 
 def gen_data(n, K, workers, per_job=100, first_seed=0):
@@ -42,7 +42,13 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--data", default="/tmp/synth_train.npz")
     ap.add_argument("--out", default="tests/golden/synth_tracker.npz")
+    ap.add_argument("--device", default="cpu", help="cpu | cuda: torch device of the training loop (the fixture was trained on the MI355X "
+                                                     "box through PyTorch-ROCm: a test-fixture generator may use any tool; the PRODUCT never sees this)")
+    ap.add_argument("--eval-every", type=int, default=100)
     ap.add_argument("--resume", default=None)
+    ap.add_argument("--trainable", default=None, help="regex of the trained state_dict keys (default: TRAINABLE above)")
+    ap.add_argument("--rot-weight", type=float, default=1.0, help="weight of the rotation loss (problems.py:90-91 loss_weights)")
+    ap.add_argument("--rot-fc-scale", type=float, default=1.0, help="multiply the (resumed) rot_out FC weights once, before training")
     args = ap.parse_args()
     import torch
     from oracle import free_run as FR, se3_oracle as O, synth_track as ST
@@ -57,21 +63,22 @@ def main():
         np.savez(args.data, **data)
         print("generated %d samples in %.0f s" % (len(data["zA"]), time.time() - t0), flush=True)
     n = len(data["zA"]) - args.val
-    T = {k: torch.from_numpy(v) for k, v in data.items()}
+    dev = torch.device(args.device)
+    T = {k: torch.from_numpy(v if v.dtype != np.uint16 else v.astype(np.int32)).to(dev) for k, v in data.items()}
 
     def tensors(idx):
-        dA = ST.offset_depth_torch(T["depthA"][idx].to(torch.int32), T["zA"][idx], torch)
-        dB = ST.offset_depth_torch(T["depthB"][idx].to(torch.int32), T["zA"][idx], torch)
+        dA = ST.offset_depth_torch(T["depthA"][idx], T["zA"][idx], torch)
+        dB = ST.offset_depth_torch(T["depthB"][idx], T["zA"][idx], torch)
         A = torch.cat([T["rgbA"][idx].to(torch.float32), dA[..., None]], 3)
         B = torch.cat([T["rgbB"][idx].to(torch.float32), dB[..., None]], 3)
         return A, B
 
     # mean / std per channel over (a sample of) the training set, A then B (mean.npy / std.npy layout, predict.py:657-658)
-    A, B = tensors(torch.arange(0, min(n, 1000)))
-    mean = torch.cat([A.mean((0, 1, 2)), B.mean((0, 1, 2))]).double().numpy()
-    std = torch.cat([A.std((0, 1, 2)), B.std((0, 1, 2))]).double().numpy()
+    A, B = tensors(torch.arange(0, min(n, 1000), device=dev))
+    mean = torch.cat([A.mean((0, 1, 2)), B.mean((0, 1, 2))]).double().cpu().numpy()
+    std = torch.cat([A.std((0, 1, 2)), B.std((0, 1, 2))]).double().cpu().numpy()
     print("mean", mean.round(2), "std", std.round(2), flush=True)
-    mean_t, std_t = torch.from_numpy(mean).float(), torch.from_numpy(std).float()
+    mean_t, std_t = torch.from_numpy(mean).float().to(dev), torch.from_numpy(std).float().to(dev)
 
     def batch(idx):
         A, B = tensors(idx)
@@ -88,7 +95,10 @@ def main():
         for k in z.files:
             if k.startswith("w:"):
                 sd[k[2:]] = torch.from_numpy(z[k].astype(np.float32))
-    pat = re.compile(TRAINABLE)
+    if args.rot_fc_scale != 1.0:
+        sd["rot_out.0.weight"] = sd["rot_out.0.weight"] * args.rot_fc_scale
+    sd = type(sd)((k, v.to(dev)) for k, v in sd.items())
+    pat = re.compile(args.trainable or TRAINABLE)
     params = []
     for k, v in sd.items():
         if v.dtype == torch.float32 and pat.search(k) and "running" not in k:
@@ -99,7 +109,7 @@ def main():
     opt = torch.optim.Adam(params, lr=args.lr)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=args.lr, total_steps=args.steps, pct_start=0.15)
     rng = np.random.default_rng(0)
-    val_idx = torch.arange(n, n + args.val)
+    val_idx = torch.arange(n, n + args.val, device=dev)
 
     def evaluate():
         with torch.no_grad():
@@ -117,27 +127,27 @@ def main():
             return float(et.mean()), float(er.mean()), ratio_t, ratio_r
 
     def save(path, val):
-        out = {"mean": mean, "std": std, "base_seed": BASE_SEED, "val": np.array(val), "trainable": TRAINABLE}
+        out = {"mean": mean, "std": std, "base_seed": BASE_SEED, "val": np.array(val), "trainable": args.trainable or TRAINABLE}
         for k, v in sd.items():
             if v.requires_grad:
-                out["w:" + k] = v.detach().numpy().astype(np.float16)
+                out["w:" + k] = v.detach().cpu().numpy().astype(np.float16)
         np.savez_compressed(path, **out)
 
     t0 = time.time()
     for step in range(args.steps):
-        idx = torch.from_numpy(rng.choice(n, args.batch, replace=False))
+        idx = torch.from_numpy(rng.choice(n, args.batch, replace=False)).to(dev)
         A, B, lt, lr_ = batch(idx)
         o = fwd(sd, A, B)
         loss_t = ((o["trans"] - lt) ** 2).mean()
         loss_r = ((o["rot"] - lr_) ** 2).mean()
-        loss = loss_t + loss_r
+        loss = loss_t + args.rot_weight * loss_r
         opt.zero_grad()
         loss.backward()
         opt.step()
         sched.step()
-        if step % 10 == 0:
+        if step % (10 if args.device == "cpu" else 100) == 0:
             print("step %4d  loss trans %.4f rot %.4f   %.0f s" % (step, float(loss_t.detach()), float(loss_r.detach()), time.time() - t0), flush=True)
-        if step % 100 == 99 or step == args.steps - 1:
+        if step % args.eval_every == args.eval_every - 1 or step == args.steps - 1:
             val = evaluate()
             print("   val |d trans| %.4f |d rot| %.4f  residual ratio trans %.3f rot %.3f" % val, flush=True)
             save(args.out, val)
