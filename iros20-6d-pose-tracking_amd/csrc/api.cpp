@@ -36,7 +36,7 @@ enum { MAX_LAUNCHES = 24, MAX_SLOTS = 64 };
 struct GraphKey {
   const void *A, *B, *trans, *rot, *poseA, *poseB, *blob;
   int n, layout, prec, wino_min_batch, wino_tile, keep, wino64, wino64_fill;
-  int small_kernels, splitk_fused, wino_fuse, gemmp;   // every switch that selects a kernel family (a graph captured under another
+  int small_kernels, splitk_fused, wino_fuse, gemmp, tail_parts;   // every switch that selects a kernel family (a graph captured under another
                                                        // setting must not be replayed)
   double tn, rn;
   bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
@@ -66,7 +66,7 @@ struct se3tn_ctx {
                                                 // in-place residual update cannot change format)
   const float* head_final = nullptr;            // what the tail of the last infer read
   float* logits = nullptr;                      // [mb,6]
-  float* fcpart = nullptr;                      // [mb,2,8,3] partial FC dot products of the fused Winograd tail
+  float* fcpart = nullptr;                      // [mb,2,<=32,3] partial FC dot products (fused Winograd tail: 8 slices per head; tail_kernel 8; tail_parts_kernel 32)
   bool keep_intermediates = false;              // se3tn_keep_intermediates: fused blocks also store ab_t / head_t / head
   int auto_tile_override[2] = {0, 0};           // SE3TN_WINOGRAD_AUTO_TILE_AB2 / _HEADS = 4 | 6: what AUTO picks per block (rounding studies)
   int trunk_kernel = 1;                         // SE3TN_TRUNK_KERNEL = 2: the register-V trunk experiment (only in -DSE3TN_TRUNK_REGV=1 builds)
@@ -74,6 +74,7 @@ struct se3tn_ctx {
   bool wino_fuse = true;                        // whole residual blocks as one fused launch sequence (SE3TN_WINOGRAD_FUSE=0: conv by conv)
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
   int* splitk_sem = nullptr;                    // [2 x SE3TN_SPLITK_MAX_TILES] arrival / seen counters of the fused split-K reduction (zero between launches)
+  bool tail_parts = true;                       // SE3TN_TAIL_PARTS=0 (developer switch): batch 1-5 keeps conv_reduce + tail_kernel after the last head conv
   bool small_kernels = true;                    // SE3TN_SMALL_KERNELS=0 (developer switch): batch 1-5 through the split-K kernels only
   bool splitk_fused = false;                    // SE3TN_SPLITK_FUSED=1 (developer switch): the reduction inside the split-K launch -- bitwise the same results,
                                                 // but SLOWER on this chip (363 vs 268 us per batch-1 forward: EXPERIMENTS item 41), so off
@@ -369,7 +370,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
         {&c->ab, padded(S3, 256), true},       {&c->ab_t, padded(S3, 256), true},
         {&c->head, padded(S4, 1024), true},    {&c->head_t, padded(S4, 1024), true},
         {&c->head_f, padded(S4, 1024), true},
-        {&c->logits, mb * 6, true},           {&c->fcpart, mb * 48, true}};
+        {&c->logits, mb * 6, true},           {&c->fcpart, mb * 192, true}};
     for (auto& b : bufs) {
       e = hipMalloc((void**)b.p, b.words * sizeof(float));
       if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(workspace)"); }
@@ -386,6 +387,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
     if (e == hipSuccess) e = hipMemset(c->tail_arrive, 0, sizeof(int) * c->max_batch);
     if (const char* sf = std::getenv("SE3TN_SPLITK_FUSED")) c->splitk_fused = std::atoi(sf) != 0;
     if (const char* sk = std::getenv("SE3TN_SMALL_KERNELS")) c->small_kernels = std::atoi(sk) != 0;
+    if (const char* tp = std::getenv("SE3TN_TAIL_PARTS")) c->tail_parts = std::atoi(tp) != 0;
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(split-K workspace)"); }
     e = hipMalloc((void**)&c->zbuf, sizeof(unsigned long long) * RES * RES);
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(zbuf)"); }
@@ -715,7 +717,7 @@ static int infer_graph_or_launch(se3tn_ctx* c, const float* A, const float* B, i
   key.wino_min_batch = c->wino_min_batch; key.wino_tile = c->wino_tile; key.keep = c->keep_intermediates ? 1 : 0;
   key.wino64 = c->wino64_min_batch; key.wino64_fill = c->wino64_min_fill; key.tn = c->tn; key.rn = c->rn;
   key.small_kernels = c->small_kernels ? 1 : 0; key.splitk_fused = c->splitk_fused ? 1 : 0; key.wino_fuse = c->wino_fuse ? 1 : 0;
-  key.gemmp = c->gemmp;
+  key.gemmp = c->gemmp; key.tail_parts = c->tail_parts ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   for (auto& g : c->graphs) {
     if (!(g.key == key)) continue;
@@ -812,6 +814,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
     HIPCHK((hipError_t)prof_mark(c, st, "maxpool3x3s2", false));
   }
 
+  bool skip_reduce = false;   // set around the last head conv when tail_parts_kernel consumes its partial sums
   auto conv = [&](ConvId id, const float* in, int in_ld, int in_gs, const float* res, int res_ld, int res_gs,
                   float* out, int out_ld, int out_gs, int hin, int stride, int epi, const char* name) -> int {
     const Conv3& s = conv_specs()[id];
@@ -853,6 +856,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
     } a.res = res; a.out = out; a.part = c->part; a.part_bytes = c->part_bytes;
     a.sem = c->splitk_fused ? c->splitk_sem : nullptr;
     a.small_ok = c->small_kernels ? 1 : 0;
+    a.skip_reduce = skip_reduce ? 1 : 0;
     a.in_ld = in_ld; a.res_ld = res_ld; a.out_ld = out_ld;
     a.H = hin; a.W = hin; a.Ho = (hin - 1) / stride + 1; a.Wo = a.Ho;
     a.M = n * a.Ho * a.Wo;
@@ -928,10 +932,26 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
   } else {
     if ((rc = conv(LH2_1, c->head, 1024, 512, nullptr, 0, 0, c->head_t, 1024, 512, S4, 1, 0, "trans|rot conv2.conv1"))) return rc;
     float* head_out = fast ? c->head_f : c->head;
-    if ((rc = conv(LH2_2, c->head_t, 1024, 512, c->head, 1024, 512, head_out, 1024, 512, S4, 1, 1, "trans|rot conv2.conv2"))) return rc;
-    c->head_final = head_out;
-    HIPCHK(launch_tail(head_out, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st, c->fcpart, c->tail_arrive, c->tail_flag, c->tail_seq));
-    HIPCHK((hipError_t)prof_mark(c, st, "tail avgpool+fc+tanh+pose", false));
+    // batch 1-5 (conv_slices_small: 8 partial-sum slices per output): the tail adds the slices itself -- no conv_reduce launch, the
+    // final head map is not written (se3tn_keep_intermediates keeps the old sequence).  Same predicate as launch_conv3x3's.
+    const bool parts_tail = !fast && c->small_kernels && c->tail_parts && !c->keep_intermediates && c->part && n <= SE3TN_SLICES_SMALL_MAX_N &&
+                            conv_slices_small_count(512, 1, S4) == 8 &&
+                            (size_t)8 * 2 * n * S4 * S4 * 512 * sizeof(float) <= c->part_bytes && !c->splitk_fused;
+    skip_reduce = parts_tail;
+    rc = conv(LH2_2, c->head_t, 1024, 512, c->head, 1024, 512, head_out, 1024, 512, S4, 1, 1, "trans|rot conv2.conv2");
+    skip_reduce = false;
+    if (rc) return rc;
+    if (parts_tail) {
+      c->head_final = nullptr;     // (not materialised in this configuration)
+      const int M = n * S4 * S4;
+      HIPCHK(launch_tail_parts(c->part, 8, (size_t)2 * M * 512, M, W + L.conv_b[LH2_2], c->head, 1024, W + L.fc_w, W + L.fc_b, c->logits, trans,
+                               rot, poseA, poseB, c->tn, c->rn, n, st, c->fcpart, c->tail_arrive, c->tail_flag, c->tail_seq));
+      HIPCHK((hipError_t)prof_mark(c, st, "tail slices+avgpool+fc+tanh+pose", false));
+    } else {
+      c->head_final = head_out;
+      HIPCHK(launch_tail(head_out, W + L.fc_w, W + L.fc_b, c->logits, trans, rot, poseA, poseB, c->tn, c->rn, n, st, c->fcpart, c->tail_arrive, c->tail_flag, c->tail_seq));
+      HIPCHK((hipError_t)prof_mark(c, st, "tail avgpool+fc+tanh+pose", false));
+    }
   }
   if (c->prof) c->slot_launches[slot] = c->n_launch;
   return SE3TN_OK;

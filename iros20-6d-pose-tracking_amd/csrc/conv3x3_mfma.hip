@@ -845,9 +845,7 @@ static int pick_slices(const ConvArgs& a, int cin, int cout, int big_tile_rows, 
 #define SE3TN_CONV64_SMALL_MAX_N 5   // the trunk convs of up to this many pairs take conv64_small_kernel (0: never).  Measured 2 vs 5:
                                      // 8.6k -> 9.6k / 10.2k -> 11.0k / 10.8k -> 11.2k pairs/s at 3 / 4 / 5 pairs (one stream)
 #endif
-#ifndef SE3TN_SLICES_SMALL_MAX_N
-#define SE3TN_SLICES_SMALL_MAX_N 5   // up to this many pairs the 128 .. 512-channel convs take conv_slices_small_kernel (0: never)
-#endif
+// (SE3TN_SLICES_SMALL_MAX_N: se3tn_internal.h)
 hipError_t launch_conv3x3(const ConvArgs& a0, int cin, int cout, int stride, int epi, hipStream_t st) {
   ConvArgs a = a0;
   if (!a.fast && cin == 64 && cout == 64 && stride == 1 && a.W == 44 && a.H == 44 && epi != 2 && a.M % (44 * 44) == 0 &&
@@ -862,6 +860,7 @@ hipError_t launch_conv3x3(const ConvArgs& a0, int cin, int cout, int stride, int
       a.sem = nullptr;
       hipError_t e = launch_conv_slices_small(a, cin, stride, st);
       if (e != hipSuccess) return e;
+      if (a.skip_reduce) return hipSuccess;              // (the tail adds the slices: kernels_misc.hip tail_parts_kernel)
       if (epi == 0) launch_reduce<0, MM_F32, FMT_F32, FMT_F32>(a, cout, st);
       else if (epi == 1) launch_reduce<1, MM_F32, FMT_F32, FMT_F32>(a, cout, st);
       else launch_reduce<2, MM_F32, FMT_F32, FMT_F32>(a, cout, st);

@@ -250,6 +250,121 @@ hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, 
   return hipGetLastError();
 }
 
+// The same tail fed by the PARTIAL SUMS of the last head conv (conv_slices_small at batch 1-5: part[slice][head][n x 121][512], 8 slices)
+// instead of its reduced output map: this kernel adds the slices in slice order, the folded bias, the residual (the block's input,
+// network_modules.py:118-120) and applies the ReLU per pixel, THEN pools -- the conv_reduce_kernel launch between the conv and the tail
+// (4.4 us + a launch boundary) is gone and the 44 KB-per-pair head map is never written.  Measured before building
+// (scripts/probes/consumer_reduce.hip, profiles/r06_probe_consumer_reduce.txt): with the tail's 16 workgroups of 64 channels the eight-fold
+// reads cost 7.7 us (16 compute units cannot pull 4 MB fast enough); as 64 workgroups of 16 channels 2.2 us.  So: 64 workgroups per
+// pair (2 heads x 32 slices of 16 channels); thread (pg, col) = pixels pg and pg + 64 x channels 4 col .. 4 col + 3 (16 + 2 loads, all in
+// flight); pixel groups, then columns, added in a fixed order; fcpart[pair][head][32][3]; the last arriver finishes as above.
+__global__ __launch_bounds__(256) void tail_parts_kernel(const float* __restrict__ part, int slices, size_t slice_stride, int M,
+                                                         const float* __restrict__ bias, const float* __restrict__ res, int res_ld,
+                                                         const float* __restrict__ fc_w, const float* __restrict__ fc_b,
+                                                         float* __restrict__ logits, float* __restrict__ trans, float* __restrict__ rot,
+                                                         const double* __restrict__ poseA, double* __restrict__ poseB, double tn, double rn,
+                                                         float* __restrict__ fcpart, int* __restrict__ arrive, int* done_flag, int done_seq) {
+  __shared__ float4 psum[64][4];
+  __shared__ float4 qsum[4][4];
+  __shared__ float dots[4][3];
+  __shared__ int last;
+  constexpr int HW = S4 * S4;
+  const int i = blockIdx.x >> 6, sl64 = blockIdx.x & 63;     // pair, 16-channel slice (0-31 trans head, 32-63 rot head)
+  const int hd = sl64 >> 5, c0 = (sl64 & 31) * 16;
+  const int t = threadIdx.x, col = t & 3, pg = t >> 2;
+  const int c = c0 + col * 4;
+  const float4 b = *reinterpret_cast<const float4*>(bias + hd * 512 + c);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int p = pg + 64 * k;
+    if (p < HW) {
+      const float* src = part + ((size_t)hd * M + (size_t)i * HW + p) * 512 + c;
+      float4 v = *reinterpret_cast<const float4*>(src);
+#pragma unroll 8
+      for (int q = 1; q < slices; ++q) {                     // slice order: the reduction order of conv_reduce_kernel
+        const float4 u = *reinterpret_cast<const float4*>(src + q * slice_stride);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      const int py = p / S4, px = p - py * S4;
+      const size_t opix = ((size_t)i * (S4 + 2) + py + 1) * (S4 + 2) + px + 1;
+      const float4 r = *reinterpret_cast<const float4*>(res + opix * res_ld + hd * 512 + c);
+      v.x = fmaxf((v.x + b.x) + r.x, 0.f); v.y = fmaxf((v.y + b.y) + r.y, 0.f);       // apply_epilogue<1> of conv_reduce_kernel:
+      v.z = fmaxf((v.z + b.z) + r.z, 0.f); v.w = fmaxf((v.w + b.w) + r.w, 0.f);       // bias, then residual, then ReLU
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  psum[pg][col] = s;
+  __syncthreads();
+  if (t < 16) {                                              // 16 pixel groups per thread, then the 4 quarters: fixed order
+    const int cc = t & 3, qd = t >> 2;
+    float4 m = psum[qd * 16][cc];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 v = psum[qd * 16 + k][cc]; m.x += v.x; m.y += v.y; m.z += v.z; m.w += v.w; }
+    qsum[qd][cc] = m;
+  }
+  __syncthreads();
+  if (t < 4) {
+    float4 m = qsum[0][t];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { const float4 v = qsum[k][t]; m.x += v.x; m.y += v.y; m.z += v.z; m.w += v.w; }
+    const float inv = (float)HW;
+    m.x /= inv; m.y /= inv; m.z /= inv; m.w /= inv;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const float4 w = *reinterpret_cast<const float4*>(fc_w + (hd * 3 + o) * 512 + c0 + t * 4);
+      dots[t][o] = m.x * w.x + m.y * w.y + m.z * w.z + m.w * w.w;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    float* mine = fcpart + ((size_t)i * 64 + sl64) * 3;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const float d = ((dots[0][o] + dots[1][o]) + dots[2][o]) + dots[3][o];
+      __hip_atomic_store(mine + o, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through: another XCD reads it below
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(arrive + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 63;
+    if (last) __hip_atomic_store(arrive + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last) return;                                   // (uniform: `last` is a shared word)
+  __shared__ float outv[6];
+  if (t < 6) {
+    const int h = t / 3, o = t - h * 3;
+    const float* p = fcpart + ((size_t)i * 64 + h * 32) * 3 + o;
+    float lg = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) lg += __hip_atomic_load(p + k * 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lg += fc_b[h * 4 + o];
+    const float y = tanhf(lg);
+    logits[i * 6 + t] = lg;
+    outv[t] = y;
+    if (h == 0) { if (trans) trans[i * 3 + o] = y; }
+    else        { if (rot) rot[i * 3 + o] = y; }
+    if (done_flag) __threadfence_system();   // (se3tn_on_track: the outputs live in mapped host memory)
+  }
+  if (poseA == nullptr) return;
+  __syncthreads();
+  if (t == 0) {
+    pose_compose(outv, poseA + (size_t)i * 16, poseB + (size_t)i * 16, tn, rn);
+    if (done_flag && i == 0) {
+      __threadfence_system();
+      __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+hipError_t launch_tail_parts(const float* part, int slices, size_t slice_stride, int M, const float* bias, const float* res, int res_ld,
+                             const float* fc_w, const float* fc_b, float* logits, float* trans, float* rot, const double* poseA,
+                             double* poseB, double tn, double rn, int n, hipStream_t st, float* fcpart, int* arrive, int* done_flag,
+                             int done_seq) {
+  hipLaunchKernelGGL(tail_parts_kernel, dim3(n * 64), dim3(256), 0, st, part, slices, slice_stride, M, bias, res, res_ld, fc_w, fc_b,
+                     logits, trans, rot, poseA, poseB, tn, rn, fcpart, arrive, done_flag, done_seq);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void padded_nhwc_to_nchw_kernel(const float* __restrict__ in,
                                                                    float* __restrict__ out, int h, int w,

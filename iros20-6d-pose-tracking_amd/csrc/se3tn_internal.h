@@ -154,6 +154,7 @@ struct ConvArgs {
   // nullptr = separate conv_reduce_kernel launch.  epi / outf / resf: the epilogue the in-kernel reduction applies
   int* sem;
   int epi, outf, resf, rpt;   // rpt: reduce workgroups per output tile
+  int skip_reduce;            // conv_slices_small only: the caller consumes the partial sums itself (tail_parts_kernel): no conv_reduce launch
   int small_ok;               // the batch-1-5 kernel family (conv64_small, conv_slices_small) may be used (SE3TN_SMALL_KERNELS=0 switches them off)
   // f16x3 mode: per-cout power-of-two weight scale (acc * wscale = true sum), overflow flag,
   // fast = 0 (f32 everywhere) | 1 | 2 (see launch_conv3x3)
@@ -268,11 +269,19 @@ hipError_t launch_stem_pool_small(const float* inA, const float* inB, const floa
 hipError_t launch_conv64_small(const ConvArgs& a, int n, int epi, hipStream_t st);
 // the 128 .. 512-channel convs at batch 1-5: 128 pixels x 32 couts x one channel slice with all nine taps per workgroup
 // (conv_slices_small.hip); partial sums for conv_reduce_kernel
+#ifndef SE3TN_SLICES_SMALL_MAX_N
+#define SE3TN_SLICES_SMALL_MAX_N 5   // up to this many pairs the 128 .. 512-channel convs take conv_slices_small_kernel (0: never)
+#endif
 int conv_slices_small_count(int cin, int stride, int H);
 hipError_t launch_conv_slices_small(const ConvArgs& a, int cin, int stride, hipStream_t st);
 hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, float* logits,
                        float* trans, float* rot, const double* poseA, double* poseB, double tn,
                        double rn, int n, hipStream_t st, float* fcpart, int* arrive, int* done_flag = nullptr, int done_seq = 0);
+// the same fed by the 8 partial-sum slices of the last head conv at batch 1-5 (no conv_reduce launch in between); fcpart [n][64][3]
+hipError_t launch_tail_parts(const float* part, int slices, size_t slice_stride, int M, const float* bias, const float* res, int res_ld,
+                             const float* fc_w, const float* fc_b, float* logits, float* trans, float* rot, const double* poseA,
+                             double* poseB, double tn, double rn, int n, hipStream_t st, float* fcpart, int* arrive, int* done_flag = nullptr,
+                             int done_seq = 0);
 // padded [n,h+2,w+2,c] NHWC interior -> [n,c,h,w]
 // split != 0: the source holds split rows (32 f16 hi | 32 f16 lo per 32-channel chunk)
 hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, int split,

@@ -554,7 +554,7 @@ def _finish_tracked(tracks, problems, frames, seeds, control_seeds, se3, metrics
     pb0 = problems[seeds[0]]
     pts = model_points_of(pb0.mesh, se3)
     out = {"what": "synthetic tracking problem with ground truth (oracle/synth_track.py): an ellipsoid with a smooth colour pattern moves "
-                   "4-7 mm and 3-8 degrees per frame in front of structured backgrounds; stand-in weights TRAINED on that problem "
+                   "4-7 mm and 3-4.5 degrees per frame in front of structured backgrounds; stand-in weights TRAINED on that problem "
                    "(tests/golden/synth_tracker.npz: the pretrained YCB weights are not available offline); the loop of predict.py:"
                    "416-420 unmodified: start at the ground-truth pose of frame 0, prev_pose <- on_track(prev_pose, frame).  Two "
                    "INDEPENDENT runs of that loop -- HIP tracker / CPU oracle -- and the oracle against itself (channels-last control)",

@@ -149,6 +149,20 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 176 * 176; ++i) sd += hDA[i] * (unsigned long long)(1 + i % 5);
     printf("track imageA_rgb=%llu imageA_depth=%llu bbox=%d,%d,%d,%d,%d,%d,%d,%d pose=", sa, sd, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5], bb[6], bb[7]);
     for (int i = 0; i < 16; ++i) printf("%.17g%s", pose[i], i == 15 ? "\n" : ",");
+    /* n tracks in ONE call from C (round 6): two poses of the same model over the same frame; pair 0 is the pose above */
+    {
+      const double P2[32] = {0.8, -0.6, 0, 0.01, 0.6, 0.8, 0, -0.005, 0, 0, 1, 0.6, 0, 0, 0, 1,
+                             1, 0, 0, -0.02, 0, 0.8, -0.6, 0.015, 0, 0.6, 0.8, 0.55, 0, 0, 0, 1};
+      const uint8_t* frames_rgb[2] = {hrgb, hrgb};
+      const uint16_t* frames_d[2] = {hd, hd};
+      double pose2[32];
+      float tr2[6], ro2[6];
+      int32_t bb2[16];
+      CHECK(se3tn_on_track_batch(ctx, mesh, 2, P2, Kc, 150.0, frames_rgb, frames_d, FH, FW, NULL, NULL, pose2, tr2, ro2, bb2, NULL));
+      printf("trackbatch bbox1=%d,%d,%d,%d,%d,%d,%d,%d pose0=", bb2[8], bb2[9], bb2[10], bb2[11], bb2[12], bb2[13], bb2[14], bb2[15]);
+      for (int i = 0; i < 16; ++i) printf("%.17g%s", pose2[i], i == 15 ? " pose1=" : ",");
+      for (int i = 0; i < 16; ++i) printf("%.17g%s", pose2[16 + i], i == 15 ? "\n" : ",");
+    }
     se3tn_mesh_destroy(mesh);
   }
   se3tn_destroy(ctx);

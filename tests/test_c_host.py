@@ -96,3 +96,16 @@ def test_c_host_matches_oracle(tmp_path):
     assert [int(v) for v in tf["bbox"].split(",")] == aux["bbox"].reshape(-1).tolist()
     got = np.array([float(v) for v in tf["pose"].split(",")]).reshape(4, 4)
     assert np.abs(got - want).max() < 1e-5, np.abs(got - want).max()
+    # se3tn_on_track_batch from C (n = 2, the same two-pair kernels as n = 1: bitwise the single call for pair 0; pair 1 vs the oracle)
+    lb = [l for l in out.stdout.splitlines() if l.startswith("trackbatch ")][0]
+    tb = dict(tok.split("=") for tok in lb.split()[1:])
+    pose0 = np.array([float(v) for v in tb["pose0"].split(",")]).reshape(4, 4)
+    pose1 = np.array([float(v) for v in tb["pose1"].split(",")]).reshape(4, 4)
+    assert np.array_equal(pose0, got)
+    P1 = np.array([[1, 0, 0, -0.02], [0, 0.8, -0.6, 0.015], [0, 0.6, 0.8, 0.55], [0, 0, 0, 1.0]])
+    bbA = O.compute_bbox(P1, Kc, 150.0, (1000, -1000, 1000))
+    win = (int(bbA[:, 1].min()), int(bbA[:, 0].min()), int(bbA[:, 1].max()), int(bbA[:, 0].max()))
+    rgbA, depthA = SF.render_vispy(ov, on, oc, faces, P1, Kc, win, numpy_rule="numpy1")
+    want1, aux1 = O.on_track(sd, P1, rgb, hd, rgbA, depthA, Kc, 150.0, mean, std)
+    assert [int(v) for v in tb["bbox1"].split(",")] == aux1["bbox"].reshape(-1).tolist()
+    assert np.abs(pose1 - want1).max() < 1e-5, np.abs(pose1 - want1).max()
