@@ -308,7 +308,9 @@ int se3tn_debug_buffer(se3tn_ctx* ctx, const char* name, const float** ptr, int3
 /* The fused Winograd blocks (batches of n >= the se3tn_set_winograd threshold) keep the activation between a
  * residual block's two convolutions in LDS and reduce the heads' last activation in registers: "ab_t", "head_t"
  * and "head" are then NOT written.  on != 0 makes those kernels store them as well (tests, feature inspection);
- * results are bit-identical either way. */
+ * results are bit-identical either way.  At 1-5 pairs the batch-1 kernel family never writes the un-pooled "stem" map nor the
+ * final "head" map (the tail adds the last conv's partial sums itself): on != 0 selects, for those two stages, the general kernels
+ * that do write them -- same tolerances, another summation order (not the same bits as the default at 1-5 pairs). */
 int se3tn_keep_intermediates(se3tn_ctx* ctx, int on);
 /* stream-ordered device-to-device copy (lets a ctypes host wrap the raw pointers above into its
  * own tensors without a second HIP binding) */

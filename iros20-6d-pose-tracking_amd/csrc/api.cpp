@@ -74,6 +74,7 @@ struct se3tn_ctx {
   bool wino_fuse = true;                        // whole residual blocks as one fused launch sequence (SE3TN_WINOGRAD_FUSE=0: conv by conv)
   float* part = nullptr;                        // split-K partial sums (small-batch latency path)
   int* splitk_sem = nullptr;                    // [2 x SE3TN_SPLITK_MAX_TILES] arrival / seen counters of the fused split-K reduction (zero between launches)
+  int tail_parts_ch = 16;                       // SE3TN_TAIL_PARTS=2: 32 workgroups x 32 channels per pair instead of 64 x 16 (developer A/B)
   bool tail_parts = true;                       // SE3TN_TAIL_PARTS=0 (developer switch): batch 1-5 keeps conv_reduce + tail_kernel after the last head conv
   bool small_kernels = true;                    // SE3TN_SMALL_KERNELS=0 (developer switch): batch 1-5 through the split-K kernels only
   bool splitk_fused = false;                    // SE3TN_SPLITK_FUSED=1 (developer switch): the reduction inside the split-K launch -- bitwise the same results,
@@ -387,7 +388,7 @@ int se3tn_create(int device, int max_batch, se3tn_ctx** out) {
     if (e == hipSuccess) e = hipMemset(c->tail_arrive, 0, sizeof(int) * c->max_batch);
     if (const char* sf = std::getenv("SE3TN_SPLITK_FUSED")) c->splitk_fused = std::atoi(sf) != 0;
     if (const char* sk = std::getenv("SE3TN_SMALL_KERNELS")) c->small_kernels = std::atoi(sk) != 0;
-    if (const char* tp = std::getenv("SE3TN_TAIL_PARTS")) c->tail_parts = std::atoi(tp) != 0;
+    if (const char* tp = std::getenv("SE3TN_TAIL_PARTS")) { c->tail_parts = std::atoi(tp) != 0; c->tail_parts_ch = std::atoi(tp) == 2 ? 32 : 16; }
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(split-K workspace)"); }
     e = hipMalloc((void**)&c->zbuf, sizeof(unsigned long long) * RES * RES);
     if (e != hipSuccess) { se3tn_destroy(c); return hipfail(e, "hipMalloc(zbuf)"); }
@@ -717,7 +718,7 @@ static int infer_graph_or_launch(se3tn_ctx* c, const float* A, const float* B, i
   key.wino_min_batch = c->wino_min_batch; key.wino_tile = c->wino_tile; key.keep = c->keep_intermediates ? 1 : 0;
   key.wino64 = c->wino64_min_batch; key.wino64_fill = c->wino64_min_fill; key.tn = c->tn; key.rn = c->rn;
   key.small_kernels = c->small_kernels ? 1 : 0; key.splitk_fused = c->splitk_fused ? 1 : 0; key.wino_fuse = c->wino_fuse ? 1 : 0;
-  key.gemmp = c->gemmp; key.tail_parts = c->tail_parts ? 1 : 0;
+  key.gemmp = c->gemmp; key.tail_parts = c->tail_parts ? c->tail_parts_ch : 0;
   hipStream_t st = (hipStream_t)stream;
   for (auto& g : c->graphs) {
     if (!(g.key == key)) continue;
@@ -945,7 +946,7 @@ static int infer_launch(se3tn_ctx* c, const float* A, const float* B, int n, int
       c->head_final = nullptr;     // (not materialised in this configuration)
       const int M = n * S4 * S4;
       HIPCHK(launch_tail_parts(c->part, 8, (size_t)2 * M * 512, M, W + L.conv_b[LH2_2], c->head, 1024, W + L.fc_w, W + L.fc_b, c->logits, trans,
-                               rot, poseA, poseB, c->tn, c->rn, n, st, c->fcpart, c->tail_arrive, c->tail_flag, c->tail_seq));
+                               rot, poseA, poseB, c->tn, c->rn, n, st, c->fcpart, c->tail_arrive, c->tail_flag, c->tail_seq, c->tail_parts_ch));
       HIPCHK((hipError_t)prof_mark(c, st, "tail slices+avgpool+fc+tanh+pose", false));
     } else {
       c->head_final = head_out;

@@ -258,56 +258,62 @@ hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, 
 // reads cost 7.7 us (16 compute units cannot pull 4 MB fast enough); as 64 workgroups of 16 channels 2.2 us.  So: 64 workgroups per
 // pair (2 heads x 32 slices of 16 channels); thread (pg, col) = pixels pg and pg + 64 x channels 4 col .. 4 col + 3 (16 + 2 loads, all in
 // flight); pixel groups, then columns, added in a fixed order; fcpart[pair][head][32][3]; the last arriver finishes as above.
-__global__ __launch_bounds__(256) void tail_parts_kernel(const float* __restrict__ part, int slices, size_t slice_stride, int M,
+template <int CH, int SLICES>      // channels per workgroup (16 | 32), partial-sum slices
+__global__ __launch_bounds__(256) void tail_parts_kernel(const float* __restrict__ part, size_t slice_stride, int M,
                                                          const float* __restrict__ bias, const float* __restrict__ res, int res_ld,
                                                          const float* __restrict__ fc_w, const float* __restrict__ fc_b,
                                                          float* __restrict__ logits, float* __restrict__ trans, float* __restrict__ rot,
                                                          const double* __restrict__ poseA, double* __restrict__ poseB, double tn, double rn,
                                                          float* __restrict__ fcpart, int* __restrict__ arrive, int* done_flag, int done_seq) {
-  __shared__ float4 psum[64][4];
-  __shared__ float4 qsum[4][4];
-  __shared__ float dots[4][3];
+  constexpr int COLS = CH / 4, PGS = 256 / COLS, NSL = 512 / CH, WGS = 2 * NSL;   // float4 columns, pixel groups, slices per head
+  constexpr int HW = S4 * S4, PPT = (HW + PGS - 1) / PGS;                         // pixels per thread: 2 | 4
+  __shared__ float4 psum[PGS][COLS];
+  __shared__ float4 qsum[4][COLS];
+  __shared__ float dots[COLS][3];
   __shared__ int last;
-  constexpr int HW = S4 * S4;
-  const int i = blockIdx.x >> 6, sl64 = blockIdx.x & 63;     // pair, 16-channel slice (0-31 trans head, 32-63 rot head)
-  const int hd = sl64 >> 5, c0 = (sl64 & 31) * 16;
-  const int t = threadIdx.x, col = t & 3, pg = t >> 2;
+  const int i = blockIdx.x / WGS, slw = blockIdx.x - i * WGS;     // pair, CH-channel slice (first half: trans head, second half: rot head)
+  const int hd = slw / NSL, c0 = (slw - hd * NSL) * CH;
+  const int t = threadIdx.x, col = t % COLS, pg = t / COLS;
   const int c = c0 + col * 4;
   const float4 b = *reinterpret_cast<const float4*>(bias + hd * 512 + c);
+  // every load of this thread first (PPT x (SLICES + 1), all in flight), then the sums in slice order
+  float4 v[PPT][SLICES], r[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = min(pg + PGS * k, HW - 1);
+    const float* src = part + ((size_t)hd * M + (size_t)i * HW + p) * 512 + c;
+#pragma unroll
+    for (int q = 0; q < SLICES; ++q) v[k][q] = *reinterpret_cast<const float4*>(src + q * slice_stride);
+    const int py = p / S4, px = p - py * S4;
+    const size_t opix = ((size_t)i * (S4 + 2) + py + 1) * (S4 + 2) + px + 1;
+    r[k] = *reinterpret_cast<const float4*>(res + opix * res_ld + hd * 512 + c);
+  }
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int p = pg + 64 * k;
-    if (p < HW) {
-      const float* src = part + ((size_t)hd * M + (size_t)i * HW + p) * 512 + c;
-      float4 v = *reinterpret_cast<const float4*>(src);
-#pragma unroll 8
-      for (int q = 1; q < slices; ++q) {                     // slice order: the reduction order of conv_reduce_kernel
-        const float4 u = *reinterpret_cast<const float4*>(src + q * slice_stride);
-        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-      }
-      const int py = p / S4, px = p - py * S4;
-      const size_t opix = ((size_t)i * (S4 + 2) + py + 1) * (S4 + 2) + px + 1;
-      const float4 r = *reinterpret_cast<const float4*>(res + opix * res_ld + hd * 512 + c);
-      v.x = fmaxf((v.x + b.x) + r.x, 0.f); v.y = fmaxf((v.y + b.y) + r.y, 0.f);       // apply_epilogue<1> of conv_reduce_kernel:
-      v.z = fmaxf((v.z + b.z) + r.z, 0.f); v.w = fmaxf((v.w + b.w) + r.w, 0.f);       // bias, then residual, then ReLU
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  for (int k = 0; k < PPT; ++k) {
+    if (pg + PGS * k < HW) {
+      float4 a = v[k][0];
+#pragma unroll
+      for (int q = 1; q < SLICES; ++q) { a.x += v[k][q].x; a.y += v[k][q].y; a.z += v[k][q].z; a.w += v[k][q].w; }   // conv_reduce_kernel's order
+      a.x = fmaxf((a.x + b.x) + r[k].x, 0.f); a.y = fmaxf((a.y + b.y) + r[k].y, 0.f);     // bias, then residual, then ReLU
+      a.z = fmaxf((a.z + b.z) + r[k].z, 0.f); a.w = fmaxf((a.w + b.w) + r[k].w, 0.f);     // (apply_epilogue<1>)
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
   }
   psum[pg][col] = s;
   __syncthreads();
-  if (t < 16) {                                              // 16 pixel groups per thread, then the 4 quarters: fixed order
-    const int cc = t & 3, qd = t >> 2;
-    float4 m = psum[qd * 16][cc];
+  if (t < 4 * COLS) {                                        // a quarter of the pixel groups per thread, then the 4 quarters: fixed order
+    const int cc = t % COLS, qd = t / COLS;
+    float4 m = psum[qd * (PGS / 4)][cc];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) { const float4 v = psum[qd * 16 + k][cc]; m.x += v.x; m.y += v.y; m.z += v.z; m.w += v.w; }
+    for (int k = 1; k < PGS / 4; ++k) { const float4 u = psum[qd * (PGS / 4) + k][cc]; m.x += u.x; m.y += u.y; m.z += u.z; m.w += u.w; }
     qsum[qd][cc] = m;
   }
   __syncthreads();
-  if (t < 4) {
+  if (t < COLS) {
     float4 m = qsum[0][t];
 #pragma unroll
-    for (int k = 1; k < 4; ++k) { const float4 v = qsum[k][t]; m.x += v.x; m.y += v.y; m.z += v.z; m.w += v.w; }
+    for (int k = 1; k < 4; ++k) { const float4 u = qsum[k][t]; m.x += u.x; m.y += u.y; m.z += u.z; m.w += u.w; }
     const float inv = (float)HW;
     m.x /= inv; m.y /= inv; m.z /= inv; m.w /= inv;
 #pragma unroll
@@ -318,14 +324,16 @@ __global__ __launch_bounds__(256) void tail_parts_kernel(const float* __restrict
   }
   __syncthreads();
   if (t == 0) {
-    float* mine = fcpart + ((size_t)i * 64 + sl64) * 3;
+    float* mine = fcpart + ((size_t)i * WGS + slw) * 3;
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
-      const float d = ((dots[0][o] + dots[1][o]) + dots[2][o]) + dots[3][o];
+      float d = dots[0][o];
+#pragma unroll
+      for (int k = 1; k < COLS; ++k) d += dots[k][o];
       __hip_atomic_store(mine + o, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through: another XCD reads it below
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = __hip_atomic_fetch_add(arrive + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 63;
+    last = __hip_atomic_fetch_add(arrive + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == WGS - 1;
     if (last) __hip_atomic_store(arrive + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
@@ -333,10 +341,13 @@ __global__ __launch_bounds__(256) void tail_parts_kernel(const float* __restrict
   __shared__ float outv[6];
   if (t < 6) {
     const int h = t / 3, o = t - h * 3;
-    const float* p = fcpart + ((size_t)i * 64 + h * 32) * 3 + o;
+    const float* p = fcpart + ((size_t)i * WGS + h * NSL) * 3 + o;
+    float pl[NSL];
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) pl[k] = __hip_atomic_load(p + k * 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float lg = 0.f;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) lg += __hip_atomic_load(p + k * 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < NSL; ++k) lg += pl[k];           // slice order
     lg += fc_b[h * 4 + o];
     const float y = tanhf(lg);
     logits[i * 6 + t] = lg;
@@ -359,9 +370,14 @@ __global__ __launch_bounds__(256) void tail_parts_kernel(const float* __restrict
 hipError_t launch_tail_parts(const float* part, int slices, size_t slice_stride, int M, const float* bias, const float* res, int res_ld,
                              const float* fc_w, const float* fc_b, float* logits, float* trans, float* rot, const double* poseA,
                              double* poseB, double tn, double rn, int n, hipStream_t st, float* fcpart, int* arrive, int* done_flag,
-                             int done_seq) {
-  hipLaunchKernelGGL(tail_parts_kernel, dim3(n * 64), dim3(256), 0, st, part, slices, slice_stride, M, bias, res, res_ld, fc_w, fc_b,
-                     logits, trans, rot, poseA, poseB, tn, rn, fcpart, arrive, done_flag, done_seq);
+                             int done_seq, int ch) {
+  if (slices != 8 || (ch != 16 && ch != 32)) return hipErrorInvalidValue;
+  if (ch == 16)
+    hipLaunchKernelGGL((tail_parts_kernel<16, 8>), dim3(n * 64), dim3(256), 0, st, part, slice_stride, M, bias, res, res_ld, fc_w, fc_b,
+                       logits, trans, rot, poseA, poseB, tn, rn, fcpart, arrive, done_flag, done_seq);
+  else
+    hipLaunchKernelGGL((tail_parts_kernel<32, 8>), dim3(n * 32), dim3(256), 0, st, part, slice_stride, M, bias, res, res_ld, fc_w, fc_b,
+                       logits, trans, rot, poseA, poseB, tn, rn, fcpart, arrive, done_flag, done_seq);
   return hipGetLastError();
 }
 

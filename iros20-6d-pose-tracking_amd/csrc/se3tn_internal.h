@@ -281,7 +281,7 @@ hipError_t launch_tail(const float* head, const float* fc_w, const float* fc_b, 
 hipError_t launch_tail_parts(const float* part, int slices, size_t slice_stride, int M, const float* bias, const float* res, int res_ld,
                              const float* fc_w, const float* fc_b, float* logits, float* trans, float* rot, const double* poseA,
                              double* poseB, double tn, double rn, int n, hipStream_t st, float* fcpart, int* arrive, int* done_flag = nullptr,
-                             int done_seq = 0);
+                             int done_seq = 0, int ch = 16);
 // padded [n,h+2,w+2,c] NHWC interior -> [n,c,h,w]
 // split != 0: the source holds split rows (32 f16 hi | 32 f16 lo per 32-channel chunk)
 hipError_t launch_padded_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, int split,

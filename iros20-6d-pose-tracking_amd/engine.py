@@ -186,7 +186,8 @@ class Engine:
 
     def keep_intermediates(self, on=True):
         """Make the fused Winograd blocks also store the activations they otherwise keep on chip ("ab_t", "head_t",
-        "head" of debug_buffer); results are bit-identical either way."""
+        "head" of debug_buffer); results are bit-identical either way -- except at 1-5 pairs, where the stem and the tail then take the
+        general kernels that write "stem" / "head" (same tolerances, another summation order)."""
         check(self.lib.se3tn_keep_intermediates(self._h, 1 if on else 0), "se3tn_keep_intermediates")
 
     def overflow(self):

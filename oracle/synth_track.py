@@ -13,7 +13,7 @@ neither is available offline).  TEST INFRASTRUCTURE ONLY: fixtures + the data th
 
 With weights trained on such samples the loop of predict.py:416-420 is CONTRACTIVE: the network re-estimates the pose from the
 observed frame every step, so a rounding difference in one frame's estimate is corrected by the next frame instead of being
-amplified (the random-init loop of oracle/closed_loop.py amplifies it: profiles/r06_free_run_random_init.json)."""
+amplified (the random-init loop of oracle/closed_loop.py amplifies it: profiles/r06_free_run.json)."""
 import numpy as np
 
 from . import closed_loop as CL
