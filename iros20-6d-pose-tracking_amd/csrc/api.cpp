@@ -1,6 +1,7 @@
 // C ABI of the hot path (include/se3tracknet.h).  Host orchestration only: every kernel lives in
 // the .hip files.  One context per (process, device).
 #include <cmath>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -1369,6 +1370,11 @@ int se3tn_on_track_batch(se3tn_ctx* c, se3tn_mesh* m, int n, const double* prev_
   if (!c->have_norm) return fail(SE3TN_E_STATE, "se3tn_on_track_batch: call se3tn_set_normalization first");
   if (stream_is_capturing((hipStream_t)stream)) return fail(SE3TN_E_STATE, "se3tn_on_track_batch: synchronous call, not capturable");
   hipStream_t st = (hipStream_t)stream;
+  static const bool trace = std::getenv("SE3TN_TRACK_TRACE") != nullptr;   // developer switch: host-side timeline of the call
+  static double tb_acc[6] = {0, 0, 0, 0, 0, 0};
+  static int tb_calls = 0;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = trace ? now() : 0.0;
   // pass 1 (host float64): the windows of every pair (predict.py:231-235 / :201-206) and the size of the staged sub-images
   std::vector<int32_t> win(8 * (size_t)n), vu(8 * (size_t)n);
   std::vector<size_t> off_rgb(n), off_d(n);
@@ -1410,17 +1416,37 @@ int se3tn_on_track_batch(se3tn_ctx* c, se3tn_mesh* m, int n, const double* prev_
   HIPCHK(hipMemcpyAsync(c->tb_inst_dev, c->tb_inst_host, sizeof(RasterInstance) * n, hipMemcpyHostToDevice, st));
   ra.inst = c->tb_inst_dev;
   HIPCHK(launch_raster(ra, st, n));
+  const double t1 = trace ? now() : 0.0;
   // the frames' windows: staged through pinned memory while the rasteriser runs, ONE copy with the poses in front
   uint8_t* hp = c->tb_stage_host;
   std::memcpy(hp, prev_poses, (size_t)n * 128);
-  for (int i = 0; i < n; ++i) {
-    const int x0 = geo[4 * i], y0 = geo[4 * i + 1], sw = geo[4 * i + 2], sh = geo[4 * i + 3];
-    if (sw < 0) { std::memset(hp + off_rgb[i], 0, 3); std::memset(hp + off_d[i], 0, 2); continue; }
-    for (int y = 0; y < sh; ++y) {
-      std::memcpy(hp + off_rgb[i] + (size_t)y * sw * 3, rgb[i] + ((size_t)(y0 + y) * W + x0) * 3, (size_t)sw * 3);
-      std::memcpy(hp + off_d[i] + (size_t)y * sw * 2, depth[i] + (size_t)(y0 + y) * W + x0, (size_t)sw * 2);
+  auto stage_pairs = [&](int i0, int i1) {
+    for (int i = i0; i < i1; ++i) {
+      const int x0 = geo[4 * i], y0 = geo[4 * i + 1], sw = geo[4 * i + 2], sh = geo[4 * i + 3];
+      if (sw < 0) { std::memset(hp + off_rgb[i], 0, 3); std::memset(hp + off_d[i], 0, 2); continue; }
+      for (int y = 0; y < sh; ++y) {
+        std::memcpy(hp + off_rgb[i] + (size_t)y * sw * 3, rgb[i] + ((size_t)(y0 + y) * W + x0) * 3, (size_t)sw * 3);
+        std::memcpy(hp + off_d[i] + (size_t)y * sw * 2, depth[i] + (size_t)(y0 + y) * W + x0, (size_t)sw * 2);
+      }
     }
+  };
+  // above ~3 MB the row-wise gather is worth helper threads (12.8 MB at 64 tracks: 0.9 ms on one core); SE3TN_STAGE_THREADS = 1 .. 8
+  // (default 4) sets the number of threads incl. the caller's
+  static const int stage_threads = [] {
+    const char* e = std::getenv("SE3TN_STAGE_THREADS");
+    const int v = e ? std::atoi(e) : 4;
+    return v < 1 ? 1 : (v > 8 ? 8 : v);
+  }();
+  const int nth = bytes > ((size_t)3 << 20) ? (stage_threads < n ? stage_threads : n) : 1;
+  if (nth > 1) {
+    std::vector<std::thread> helpers;
+    for (int k = 1; k < nth; ++k) helpers.emplace_back(stage_pairs, (int)((long long)n * k / nth), (int)((long long)n * (k + 1) / nth));
+    stage_pairs(0, n / nth);
+    for (auto& h : helpers) h.join();
+  } else {
+    stage_pairs(0, n);
   }
+  const double t2 = trace ? now() : 0.0;
   HIPCHK(hipMemcpyAsync(c->tb_stage_dev, hp, bytes, hipMemcpyHostToDevice, c->trk_copy_stream));
   HIPCHK(hipEventRecord(c->trk_copy_event, c->trk_copy_stream));
   HIPCHK(hipStreamWaitEvent(st, c->trk_copy_event, 0));
@@ -1446,8 +1472,20 @@ int se3tn_on_track_batch(se3tn_ctx* c, se3tn_mesh* m, int n, const double* prev_
   if (rc == SE3TN_OK)
     rc = se3tn_infer(c, c->inA, c->inB, n, SE3TN_NHWC, trans_d, rot_d, (const double*)c->tb_stage_dev, (double*)c->tb_out_dev, stream);
   if (rc != SE3TN_OK) { (void)hipStreamSynchronize(c->trk_copy_stream); return rc; }
+  const double t3 = trace ? now() : 0.0;
   HIPCHK(hipMemcpyAsync(c->tb_out_host, c->tb_out_dev, (size_t)n * 152, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if (trace) {
+    const double t4 = now();
+    const double d[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0};
+    for (int i = 0; i < 5; ++i) tb_acc[i] += d[i];
+    if (++tb_calls % 50 == 0) {
+      std::fprintf(stderr, "se3tn_on_track_batch host timeline (n = %d, mean of 50, us): bboxes + uniforms + render enqueue %.1f | staging %.1f MB %.1f | "
+                   "upload + crops + infer enqueue %.1f | wait for the device %.1f | total %.1f\n", n, tb_acc[0] / 50, bytes / 1e6, tb_acc[1] / 50,
+                   tb_acc[2] / 50, tb_acc[3] / 50, tb_acc[4] / 50);
+      for (double& v : tb_acc) v = 0;
+    }
+  }
   std::memcpy(pose_out, c->tb_out_host, (size_t)n * 128);
   if (trans_out) std::memcpy(trans_out, c->tb_out_host + (size_t)n * 128, (size_t)n * 12);
   if (rot_out) std::memcpy(rot_out, c->tb_out_host + (size_t)n * 140, (size_t)n * 12);

@@ -127,22 +127,22 @@ class SynthTrackProblem:
     ground-truth pose of frame 0 (predict.py:404-409), no anchor."""
     kind = "synth"
 
-    def __init__(self, seed, sequence, weights=None):
+    def __init__(self, seed, sequence, weights=None, regime=None):
         from . import synth_track as ST
-        self.seed, self.regime = seed, ST.REGIME
+        self.seed, self.regime = seed, regime or ST.REGIME
         self.mesh = ST.make_object()
         self.K = camera_matrix()
-        self.tn, self.rn = ST.TRANS_NORMALIZER, ST.ROT_NORMALIZER
+        self.tn, self.rn = ST.normalizers(self.regime)
         self.object_width = ST.OBJECT_WIDTH_MM
         self.sequence_path = sequence if isinstance(sequence, str) else None
         self.sequence = ST.Sequence.load(sequence) if isinstance(sequence, str) else sequence
-        self.weights_path = weights or default_synth_weights()
+        self.weights_path = weights or default_synth_weights(self.regime)
         self.sd, self.mean, self.std, self.weights_info = load_synth_weights(self.weights_path)
-        self.gt = [ST.gt_pose(seed, f) for f in range(len(self.sequence))]
+        self.gt = [ST.gt_pose(seed, f, self.regime) for f in range(len(self.sequence))]
 
     def spec(self):
         assert self.sequence_path, "save the sequence first (Sequence.save) so that the workers can load it"
-        return dict(kind=self.kind, seed=self.seed, sequence=self.sequence_path, weights=self.weights_path)
+        return dict(kind=self.kind, seed=self.seed, sequence=self.sequence_path, weights=self.weights_path, regime=self.regime)
 
     def frame(self, f):
         return self.sequence.frame(f + 1)                 # iteration f estimates the pose of camera frame f + 1 from that of frame f
@@ -160,8 +160,10 @@ class SynthTrackProblem:
         return self.gt[f]
 
 
-def default_synth_weights():
-    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "synth_tracker.npz")
+def default_synth_weights(regime=None):
+    """the trained stand-in of a normaliser regime: synth_tracker.npz (30 degrees, predict.py:586), synth_tracker_5deg.npz (predict.py:128)"""
+    name = "synth_tracker_5deg.npz" if regime == "ycb_video_5deg" else "synth_tracker.npz"
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", name)
 
 
 def load_synth_weights(path):
@@ -185,7 +187,7 @@ def problem_from_spec(spec):
     if spec["kind"] == "random_init":
         sd = {k: torch.from_numpy(np.array(v)) for k, v in spec["sd"].items()}
         return RandomInitProblem(spec["seed"], spec["regime"], sd=sd, mesh=spec["mesh"])
-    return SynthTrackProblem(spec["seed"], spec["sequence"], spec["weights"])
+    return SynthTrackProblem(spec["seed"], spec["sequence"], spec["weights"], spec.get("regime"))
 
 
 def oracle_track(job):
@@ -502,7 +504,7 @@ def against_ground_truth(track, pb, pts, metrics):
 
 
 def run_tracked(se3, frames=1000, seeds=(0, 1, 2), workers=None, metrics=None, control_seeds=(0,), weights=None, runner=None,
-                defer=False):
+                defer=False, regime=None):
     """The `free_running` block on the synthetic tracking problem WITH ground truth and trained stand-in weights
     (oracle/synth_track.py, tests/golden/synth_tracker.npz): the loop of predict.py:416-420 unmodified on both sides -- started at
     the ground-truth pose of frame 0, prev_pose <- on_track(prev_pose, frame) -- plus what configs[2] reports: ADD / ADD-S AUC of each
@@ -520,10 +522,10 @@ def run_tracked(se3, frames=1000, seeds=(0, 1, 2), workers=None, metrics=None, c
     nw, threads = runner.pool._max_workers, runner.threads
     try:
         for seed in seeds:                                  # the object patches of every frame (CPU renders), in the pool
-            seq = ST.make_sequence(seed, frames + 1, K, runner.pool)
+            seq = ST.make_sequence(seed, frames + 1, K, runner.pool, regime=regime)
             path = os.path.join(tmp, "seq_%d.npz" % seed)
             seq.save(path)
-            problems[seed] = SynthTrackProblem(seed, path, weights)
+            problems[seed] = SynthTrackProblem(seed, path, weights, regime)
         t_seq = time.time() - t_start
         handle = runner.submit(problems, frames, set(control_seeds))
     except BaseException:
@@ -554,11 +556,12 @@ def _finish_tracked(tracks, problems, frames, seeds, control_seeds, se3, metrics
     pb0 = problems[seeds[0]]
     pts = model_points_of(pb0.mesh, se3)
     out = {"what": "synthetic tracking problem with ground truth (oracle/synth_track.py): an ellipsoid with a smooth colour pattern moves "
-                   "4-7 mm and 3-4.5 degrees per frame in front of structured backgrounds; stand-in weights TRAINED on that problem "
-                   "(tests/golden/synth_tracker.npz: the pretrained YCB weights are not available offline); the loop of predict.py:"
+                   "4-7 mm and %s degrees per frame in front of structured backgrounds; stand-in weights TRAINED on that problem "
+                   "(%s: the pretrained YCB weights are not available offline); the loop of predict.py:"
                    "416-420 unmodified: start at the ground-truth pose of frame 0, prev_pose <- on_track(prev_pose, frame).  Two "
-                   "INDEPENDENT runs of that loop -- HIP tracker / CPU oracle -- and the oracle against itself (channels-last control)",
-           "frames": frames, "seeds": list(seeds), "control_seeds": list(control_seeds), "oracle_workers": nw,
+                   "INDEPENDENT runs of that loop -- HIP tracker / CPU oracle -- and the oracle against itself (channels-last control)"
+                   % ("3-4.5" if pb0.regime == "ycbineoat_30deg" else "1-1.5", os.path.join("tests", "golden", os.path.basename(pb0.weights_path))),
+           "regime": pb0.regime, "frames": frames, "seeds": list(seeds), "control_seeds": list(control_seeds), "oracle_workers": nw,
            "oracle_threads_per_worker": threads, "trans_normalizer": pb0.tn, "rot_normalizer_deg": round(pb0.rn * 180 / np.pi, 3),
            "weights": pb0.weights_info, "sequence_seconds": round(t_seq, 1)}
     out.update(_blocks(tracks, pts, metrics))
@@ -576,23 +579,27 @@ def _finish_tracked(tracks, problems, frames, seeds, control_seeds, se3, metrics
     return out
 
 
+TRACKED_REGIMES = (("ycbineoat_30deg", "synthetic_tracking_trained_weights"), ("ycb_video_5deg", "synthetic_tracking_trained_weights_5deg"))
+
+
 def run_report(se3, frames_tracked=1000, frames_random=1000, seeds=(0, 1, 2), control_seeds=(0,), workers=None):
-    """Both problem sets through ONE worker pool (bench.py's `track.free_running`): the synthetic tracking problem first (its
-    sequences are rendered in the still-idle pool), then the random-init stand-in; both sets of oracle tracks run side by side."""
-    have_weights = os.path.exists(default_synth_weights())
-    njobs = (len(seeds) + len(control_seeds)) * (2 * (frames_random > 0) + (frames_tracked > 0 and have_weights))
+    """Every problem set through ONE worker pool (bench.py's `track.free_running`): the synthetic tracking problem first, under each
+    normaliser regime that has a trained fixture (its sequences are rendered in the still-idle pool), then the random-init stand-in; all
+    sets of oracle tracks run side by side."""
+    have = [(r, k) for r, k in TRACKED_REGIMES if os.path.exists(default_synth_weights(r))] if frames_tracked > 0 else []
+    njobs = (len(seeds) + len(control_seeds)) * (2 * (frames_random > 0) + len(have))
     nw, threads = (workers, 2) if workers else default_workers(max(njobs, 1))
     runner = PairRunner(se3, nw, threads)
-    out, fin_t, fin_r = {}, None, None
+    out, fins, fin_r = {}, [], None
     try:
-        if frames_tracked > 0 and have_weights:
-            fin_t = run_tracked(se3, frames_tracked, seeds, control_seeds=control_seeds, runner=runner, defer=True)
-        elif frames_tracked > 0:
+        for regime, key in have:
+            fins.append((key, run_tracked(se3, frames_tracked, seeds, control_seeds=control_seeds, runner=runner, defer=True, regime=regime)))
+        if frames_tracked > 0 and not have:
             out["synthetic_tracking_trained_weights"] = {"skipped": "tests/golden/synth_tracker.npz not found"}
         if frames_random > 0:
             fin_r = run_free(se3, frames_random, seeds, control_seeds=control_seeds, runner=runner, defer=True)
-        if fin_t is not None:
-            out["synthetic_tracking_trained_weights"] = fin_t()
+        for key, fin in fins:
+            out[key] = fin()
         if fin_r is not None:
             out["random_init"] = fin_r()
     finally:

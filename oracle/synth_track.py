@@ -14,6 +14,8 @@ neither is available offline).  TEST INFRASTRUCTURE ONLY: fixtures + the data th
 With weights trained on such samples the loop of predict.py:416-420 is CONTRACTIVE: the network re-estimates the pose from the
 observed frame every step, so a rounding difference in one frame's estimate is corrected by the next frame instead of being
 amplified (the random-init loop of oracle/closed_loop.py amplifies it: profiles/r06_free_run.json)."""
+import os
+
 import numpy as np
 
 from . import closed_loop as CL
@@ -22,10 +24,19 @@ from . import se3_oracle as O
 
 RADII = np.array([0.060, 0.045, 0.035])
 OBJECT_WIDTH_MM = CL.OBJECT_WIDTH_MM
-REGIME = "ycbineoat_30deg"          # predict.py:586: 0.03 m, 30 degrees: the regime where a logit error reaches the pose x 0.52 and the
+REGIME = os.environ.get("SE3TN_SYNTH_REGIME", "ycbineoat_30deg")   # the default regime of this module; predict.py:586: 0.03 m, 30 degrees: the regime where a logit error reaches the pose x 0.52 and the
                                     # 1e-5 pose tolerance binds; rotations of up to 27 degrees between image A and the frame are also what
                                     # lets a rotation head learn from 320 k synthetic pairs (under 5 degrees it did not start to)
 TRANS_NORMALIZER, ROT_NORMALIZER = CL.REGIMES[REGIME]
+
+
+def normalizers(regime=None):
+    return CL.REGIMES[regime or REGIME]
+
+
+def rot_speed(regime=None):
+    """ground-truth rotation per frame scales with the normaliser: 3-4.5 degrees per frame under 30 degrees, 1-1.5 under 5"""
+    return 1.0 if (regime or REGIME) == "ycbineoat_30deg" else 1.0 / 3.0
 N_BACKGROUNDS = CL.N_DISTINCT_FRAMES
 
 
@@ -48,13 +59,13 @@ def rodrigues64(r):
     return Rotation.from_rotvec(np.asarray(r, np.float64)).as_matrix()
 
 
-def gt_pose(seed, f):
+def gt_pose(seed, f, regime=None):
     """ground-truth object-in-camera pose of frame f of sequence `seed`"""
     rng = np.random.default_rng(7000 + seed)
     R0 = rodrigues64(rng.normal(0, 0.8, 3))
     ph = rng.uniform(0, 2 * np.pi, 3)
-    w = np.array([1.20 * np.sin(2 * np.pi * f / 173.0 + ph[0]), 0.90 * np.sin(2 * np.pi * f / 211.0 + ph[1]),
-                  1.35 * np.sin(2 * np.pi * f / 139.0 + ph[2])])
+    w = rot_speed(regime) * np.array([1.20 * np.sin(2 * np.pi * f / 173.0 + ph[0]), 0.90 * np.sin(2 * np.pi * f / 211.0 + ph[1]),
+                              1.35 * np.sin(2 * np.pi * f / 139.0 + ph[2])])
     P = np.eye(4)
     P[:3, :3] = rodrigues64(w) @ R0
     P[:3, 3] = CL.anchor(f + 37 * seed)
@@ -101,7 +112,7 @@ def sequence_patches(job):
     """worker: object patches of frames [f0, f1) of sequence `seed`"""
     om = CL.oracle_mesh(make_object(job.get("subdiv", 4)))
     K = np.asarray(job["K"], np.float64)
-    return [object_patch(om, gt_pose(job["seed"], f), K) for f in range(job["f0"], job["f1"])]
+    return [object_patch(om, gt_pose(job["seed"], f, job.get("regime")), K) for f in range(job["f0"], job["f1"])]
 
 
 class Sequence:
@@ -136,8 +147,8 @@ class Sequence:
         return Sequence(int(z["seed"]), patches, int(z["offset"]))
 
 
-def make_sequence(seed, frames, K, pool=None, chunk=50, subdiv=4):
-    jobs = [dict(seed=seed, f0=f0, f1=min(f0 + chunk, frames), K=K, subdiv=subdiv) for f0 in range(0, frames, chunk)]
+def make_sequence(seed, frames, K, pool=None, chunk=50, subdiv=4, regime=None):
+    jobs = [dict(seed=seed, f0=f0, f1=min(f0 + chunk, frames), K=K, subdiv=subdiv, regime=regime) for f0 in range(0, frames, chunk)]
     parts = list(pool.map(sequence_patches, jobs)) if pool is not None else [sequence_patches(j) for j in jobs]
     return Sequence(seed, [p for part in parts for p in part])
 
@@ -152,7 +163,7 @@ def random_gt(rng):
     return P
 
 
-def perturbed(G, rng, scale=None):
+def perturbed(G, rng, scale=None, regime=None):
     """P_A and the labels such that processPredict(P_A, labels) = G (datasets.py:159-175): t_G = t_A + trans * tn,
     R_G = Rodrigues(rot * rn) R_A"""
     s = rng.uniform(0.05, 1.0) if scale is None else scale
@@ -160,8 +171,9 @@ def perturbed(G, rng, scale=None):
     rot = rng.normal(0, 1, 3)
     rot = rot / np.linalg.norm(rot) * rng.uniform(0, 0.9) * s
     A = np.eye(4)
-    A[:3, 3] = G[:3, 3] - trans * TRANS_NORMALIZER
-    A[:3, :3] = rodrigues64(rot * ROT_NORMALIZER).T @ G[:3, :3]
+    tn, rn = normalizers(regime)
+    A[:3, 3] = G[:3, 3] - trans * tn
+    A[:3, :3] = rodrigues64(rot * rn).T @ G[:3, :3]
     return A, trans.astype(np.float32), rot.astype(np.float32)
 
 
@@ -177,7 +189,7 @@ def training_samples(job):
                zA=np.empty(n, np.float64), trans=np.empty((n, 3), np.float32), rot=np.empty((n, 3), np.float32))
     for i in range(n):
         G = random_gt(rng)
-        A, trans, rot = perturbed(G, rng)
+        A, trans, rot = perturbed(G, rng, regime=job.get("regime"))
         rgb, depth = compose_frame(bgs[i % len(bgs)], object_patch(om, G, K))
         rgbA, depthA = CL.oracle_image_A(om, A, K, OBJECT_WIDTH_MM, "numpy1")
         bb = O.compute_bbox(A, K, OBJECT_WIDTH_MM, scale=(1000, 1000, 1000))

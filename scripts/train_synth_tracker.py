@@ -27,9 +27,12 @@ BASE_SEED = 0
 TRAINABLE = r"^(convA1|convB1|convA2|convB2|convB3|convAB1|convAB2)\.|\.(bn1|bn2|1)\.(weight|bias)$|^(trans_out|rot_out)\."
 
 
+REGIME = None          # set from --regime
+
+
 def gen_data(n, K, workers, per_job=100, first_seed=0, pool=None):
     from oracle import free_run as FR, synth_track as ST
-    jobs = [dict(seed=first_seed + j, n=min(per_job, n - j * per_job), K=K) for j in range((n + per_job - 1) // per_job)]
+    jobs = [dict(seed=first_seed + j, n=min(per_job, n - j * per_job), K=K, regime=REGIME) for j in range((n + per_job - 1) // per_job)]
     if pool is not None:
         parts = list(pool.map(ST.training_samples, jobs))
     else:
@@ -49,6 +52,8 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--data", default="/tmp/synth_train.npz")
     ap.add_argument("--out", default="tests/golden/synth_tracker.npz")
+    ap.add_argument("--regime", default="ycbineoat_30deg", choices=["ycbineoat_30deg", "ycb_video_5deg"],
+                    help="normalisers the labels are in: predict.py:586 (0.03 m, 30 degrees) or predict.py:128 (0.03 m, 5 degrees)")
     ap.add_argument("--device", default="cpu", help="cpu | cuda: torch device of the training loop (the fixture was trained on the MI355X "
                                                      "box through PyTorch-ROCm: a test-fixture generator may use any tool; the PRODUCT never sees this)")
     ap.add_argument("--eval-every", type=int, default=100)
@@ -58,9 +63,13 @@ def main():
                          "-- 20 k samples alone were memorised (train loss 0, held-out rotation residual ratio 0.75)")
     ap.add_argument("--resume", default=None)
     ap.add_argument("--trainable", default=None, help="regex of the trained state_dict keys (default: TRAINABLE above)")
+    ap.add_argument("--clip", type=float, default=0.0, help="> 0: clip the gradient norm (a run under the 5-degree normaliser collapsed to the zero "
+                                                           "predictor at the peak of the one-cycle schedule without it)")
     ap.add_argument("--rot-weight", type=float, default=1.0, help="weight of the rotation loss (problems.py:90-91 loss_weights)")
     ap.add_argument("--rot-fc-scale", type=float, default=1.0, help="multiply the (resumed) rot_out FC weights once, before training")
     args = ap.parse_args()
+    global REGIME
+    REGIME = args.regime
     import torch
     from oracle import free_run as FR, se3_oracle as O, synth_track as ST
     torch.set_num_threads(args.threads)
@@ -144,7 +153,7 @@ def main():
             return float(et.mean()), float(er.mean()), ratio_t, ratio_r
 
     def save(path, val):
-        out = {"mean": mean, "std": std, "base_seed": BASE_SEED, "val": np.array(val), "trainable": args.trainable or TRAINABLE}
+        out = {"mean": mean, "std": std, "base_seed": BASE_SEED, "regime": args.regime, "val": np.array(val), "trainable": args.trainable or TRAINABLE}
         for k, v in sd.items():
             if v.requires_grad:
                 out["w:" + k] = v.detach().cpu().numpy().astype(np.float16)
@@ -173,6 +182,8 @@ def main():
         loss = loss_t + args.rot_weight * loss_r
         opt.zero_grad()
         loss.backward()
+        if args.clip > 0:
+            torch.nn.utils.clip_grad_norm_(params, args.clip)
         opt.step()
         sched.step()
         if step % (10 if args.device == "cpu" else 100) == 0:

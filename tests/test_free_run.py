@@ -102,7 +102,19 @@ def test_free_running_tracks_with_trained_weights_stay_together(report):
         one size), at the level at which the oracle separates from itself under a change of memory format (median 7e-4, max 0.02 on the
         4x4; 1 mm / 1 degree), far below the tracker's own error against the ground truth,
       * score the same: ADD / ADD-S AUC against the ground truth equal to 0.01 (eval_ycb.py:45-119), as the oracle vs itself."""
-    r = report["synthetic_tracking_trained_weights"]
+    _assert_tracked(report["synthetic_tracking_trained_weights"], "ycbineoat_30deg")
+
+
+@pytest.mark.gpu
+def test_free_running_tracks_with_trained_weights_5_degree_regime(report):
+    """the same under the YCB-Video normalisers of predict.py:128 (0.03 m, 5 degrees; its own trained stand-in, 1-1.5 degrees per frame)"""
+    if "synthetic_tracking_trained_weights_5deg" not in report:
+        pytest.skip("tests/golden/synth_tracker_5deg.npz not generated")
+    _assert_tracked(report["synthetic_tracking_trained_weights_5deg"], "ycb_video_5deg")
+
+
+def _assert_tracked(r, regime):
+    assert r["regime"] == regime
     ctl, hc = r["control_oracle_vs_oracle_channels_last"], r["hip_vs_oracle_channels_last"]
     print({k: v for k, v in r.items() if k not in ("tracks_detail", "control_oracle_vs_oracle_channels_last", "hip_vs_oracle_channels_last", "what")})
     print("control", {k: v for k, v in ctl.items() if k != "tracks_detail"})
