@@ -1430,14 +1430,15 @@ int se3tn_on_track_batch(se3tn_ctx* c, se3tn_mesh* m, int n, const double* prev_
       }
     }
   };
-  // above ~3 MB the row-wise gather is worth helper threads (12.8 MB at 64 tracks: 0.9 ms on one core); SE3TN_STAGE_THREADS = 1 .. 8
-  // (default 4) sets the number of threads incl. the caller's
+  // above ~8 MB the row-wise gather is worth helper threads (measured, profiles/r06_tracker_batch_staging.txt: 13.5 MB at 64 tracks 0.34-0.43 ms
+  // on one core, 0.25 ms on four; 4.5 MB at 21 tracks 0.10 ms on one core, 0.15 ms on four -- the thread start costs more than it
+  // saves); SE3TN_STAGE_THREADS = 1 .. 8 (default 4) sets the number of threads incl. the caller's
   static const int stage_threads = [] {
     const char* e = std::getenv("SE3TN_STAGE_THREADS");
     const int v = e ? std::atoi(e) : 4;
     return v < 1 ? 1 : (v > 8 ? 8 : v);
   }();
-  const int nth = bytes > ((size_t)3 << 20) ? (stage_threads < n ? stage_threads : n) : 1;
+  const int nth = bytes > ((size_t)8 << 20) ? (stage_threads < n ? stage_threads : n) : 1;
   if (nth > 1) {
     std::vector<std::thread> helpers;
     for (int k = 1; k < nth; ++k) helpers.emplace_back(stage_pairs, (int)((long long)n * k / nth), (int)((long long)n * (k + 1) / nth));
