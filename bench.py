@@ -17,9 +17,9 @@ The JSON line carries, besides the contract fields:
   parity        the TIMED batch checked against the CPU oracle: all pairs, pre-processing bit-exact, (trans, rot)
                 and the composed pose against the north-star tolerances
   track         300-frame closed-loop Tracker.on_track stand-in for configs[2]: `per_step_parity` (the oracle evaluated at the HIP
-                track's pose every frame) and `free_running` (two independent closed loops, HIP / oracle, 1000 frames x 3 seeds: on a
-                synthetic tracking problem with ground truth and trained stand-in weights -- ADD / ADD-S AUC of both tracks -- and
-                on the random-init stand-in, each with the oracle-vs-itself control)
+                track's pose every frame) and `free_running` (two independent closed loops, HIP / oracle, 3 seeds: 1000 frames on a
+                synthetic tracking problem with ground truth and trained stand-in weights, under both normaliser regimes -- ADD / ADD-S
+                AUC of both tracks -- and 300 on the random-init stand-in, each with the oracle-vs-itself control)
   cpu_baseline  the oracle timed on this box's host cores (bounded sample)
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--stage full|net]
@@ -96,8 +96,10 @@ def main():
     ap.add_argument("--free-frames", type=int, default=1000,
                     help="frames of the FREE-RUNNING two-track comparison on the synthetic tracking problem with ground truth and "
                          "trained stand-in weights (track.free_running.synthetic_tracking_trained_weights; 0 = skip)")
-    ap.add_argument("--free-frames-random", type=int, default=1000,
-                    help="frames of the free-running comparison on the random-init stand-in (track.free_running.random_init; 0 = skip)")
+    ap.add_argument("--free-frames-random", type=int, default=300,
+                    help="frames of the free-running comparison on the random-init stand-in (track.free_running.random_init; 0 = skip).  300 by "
+                         "default: those tracks are unrelated after 5-20 frames whatever the implementation (1,000 frames x 3 seeds x every "
+                         "control: profiles/r06_free_run.json)")
     ap.add_argument("--exact-steps", action="store_true",
                     help="never extend the timed region beyond --steps (default: a region shorter than 1 s is re-run "
                          "with enough steps and BOTH are reported)")

@@ -86,3 +86,29 @@ def test_trained_stand_in_contracts_on_the_oracle():
         Q, _ = O.on_track(sd, A, rgb, depth, rgbA, depthA, K, ST.OBJECT_WIDTH_MM, mean, std, ST.TRANS_NORMALIZER, ST.ROT_NORMALIZER)
         before.append(np.linalg.norm(A[:3, 3] - G[:3, 3])); after.append(np.linalg.norm(Q[:3, 3] - G[:3, 3]))
     assert np.mean(after) < 0.5 * np.mean(before), (before, after)
+
+
+@pytest.mark.parametrize("regime", ["ycbineoat_30deg", "ycb_video_5deg"])
+def test_fixture_is_in_the_units_of_its_regime(regime):
+    """Guards a mistake round 6 made once: a "5-degree" fixture trained on 30-degree pairs looks fine against its own held-out set and has a
+    rotation gain of 1/6 on real 5-degree pairs.  On FRESH pairs of its regime a fixture's outputs must regress on the labels with gain ~1
+    and leave a one-step residual well under the label (the loop contracts)."""
+    import torch
+    path = FR.default_synth_weights(regime)
+    if not os.path.exists(path):
+        pytest.skip(os.path.basename(path) + " not generated")
+    K = FR.camera_matrix()
+    sd, mean, std, _ = FR.load_synth_weights(path)
+    d = ST.training_samples(dict(seed=4242, n=24, K=K, regime=regime))
+    A, B = [], []
+    for i in range(24):
+        P = np.eye(4); P[2, 3] = d["zA"][i]
+        a, b = O.process_data(d["rgbA"][i], d["depthA"][i], P, d["rgbB"][i], d["depthB"][i], mean, std, "numpy1")
+        A.append(a); B.append(b)
+    o = O.forward(sd, torch.from_numpy(np.stack(A)), torch.from_numpy(np.stack(B)))
+    for name, pred, lab in (("trans", o["trans"].numpy(), d["trans"]), ("rot", o["rot"].numpy(), d["rot"])):
+        gain = float((pred * lab).sum() / (lab ** 2).sum())
+        ratio = float(np.linalg.norm(pred - lab, axis=1).mean() / np.linalg.norm(lab, axis=1).mean())
+        # (30 degrees: gain 0.96-1.00, ratio 0.06 / 0.21; 5 degrees, where a rotation is a 1-pixel effect: rotation gain ~0.75, ratio ~0.5;
+        #  the wrong-units fixture: gain 0.17, ratio 0.84)
+        assert 0.6 < gain < 1.2 and ratio < 0.65, (regime, name, gain, ratio)
