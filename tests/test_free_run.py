@@ -134,10 +134,8 @@ def _assert_tracked(r, regime):
     for seed, g in r["against_ground_truth"].items():
         # the tracker tracks (AUC of ADD-S against the ground truth: eval_ycb.py:45-119) and both implementations score the same
         assert g["hip"]["reinits"] == 0 and g["oracle"]["reinits"] == 0
-        # (the 5-degree stand-in is the weaker tracker: its rotation estimate lags the 1-1.5 degrees per frame of its sequence by ~5 degrees --
-        # ADD 3.4 mm, ADD-S 2.1 mm, AUC 96.7 / 97.9 -- where the 30-degree one follows to 0.7 degrees: AUC 99.1)
-        lo_s, lo_a = (98.0, 98.0) if regime == "ycbineoat_30deg" else (97.0, 95.5)
-        assert g["oracle"]["adds_auc"] > lo_s and g["hip"]["adds_auc"] > lo_s and g["hip"]["add_auc"] > lo_a, g
+        # (measured: AUC 99.1-99.2 under 30 degrees, 99.2-99.3 under 5)
+        assert g["oracle"]["adds_auc"] > 98.0 and g["hip"]["adds_auc"] > 98.0 and g["hip"]["add_auc"] > 98.0, g
         assert g["hip"]["adds_mm_max"] < 5.0 and g["oracle"]["adds_mm_max"] < 5.0
         assert abs(g["adds_auc_hip_minus_oracle"]) < 0.05 and abs(g["add_auc_hip_minus_oracle"]) < 0.05, g
     assert r["hz_hip"] > 1000
