@@ -5,7 +5,7 @@ a separation that starts at rounding level).  GPU part: the bounds the measured 
 import numpy as np
 import pytest
 
-from oracle import closed_loop as CL, fixtures as Fx, free_run as FR
+from oracle import closed_loop as CL, free_run as FR
 
 
 @pytest.fixture(scope="module")
