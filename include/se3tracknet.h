@@ -218,12 +218,13 @@ int se3tn_render(se3tn_ctx* ctx, se3tn_mesh* mesh, const double ob_in_cam[16], c
                  const int32_t window[4], uint8_t* rgb, uint16_t* depth, void* stream);
 /* Batches of 1-5 pairs -- the regime Tracker.on_track runs in -- take kernels of their own: the four 64 -> 64 trunk convs without a
  * K split or a reduction launch (conv64_small.hip) and the 128 .. 512-channel convs as one round of 128-pixel x 32-cout x
- * channel-slice workgroups with a layer-fixed slice count (conv_slices_small.hip) at 1-5 pairs; the stem + max-pool in one launch
- * of 16-pool-pixel tiles (stem_pool_small.hip) at 1-2 pairs.  float32, same tolerances, other summation orders than the kernels
- * larger batches take: 1 and 2 pairs give a pair the same bits alone or together; from 3 pairs the stem changes kernels, so the last
- * bits of a pair's result can depend on the batch it travels in (as they do across the Winograd thresholds at 6 / 14 pairs, and in
- * the reference under cuDNN's per-shape algorithm choice, predict.py:78).  on = 0 keeps every batch size on the general kernels
- * (default 1; SE3TN_SMALL_KERNELS=0 in the environment of se3tn_create does the same). */
+ * channel-slice workgroups with a layer-fixed slice count (conv_slices_small.hip), the stem + max-pool in one launch of
+ * 16-pool-pixel tiles (stem_pool_small.hip), and a tail that adds the last conv's partial-sum slices itself (tail_parts_kernel).
+ * float32, same tolerances, other summation orders than the kernels larger batches take.  Every kernel of the family works image by
+ * image with a layer-fixed summation order: for every n <= 5 a pair has the same bits alone or in any batch (round 6; from 6 pairs the
+ * algorithms change -- Winograd thresholds at 6 / 14 pairs -- and the last bits of a pair's result depend on the batch it travels in,
+ * as in the reference under cuDNN's per-shape algorithm choice, predict.py:78).  on = 0 keeps every batch size on the general
+ * kernels (default 1; SE3TN_SMALL_KERNELS=0 in the environment of se3tn_create does the same). */
 int se3tn_set_small_kernels(se3tn_ctx* ctx, int on);
 int se3tn_get_small_kernels(const se3tn_ctx* ctx);
 /* Rasterisation rule.  OpenGL leaves sub-pixel precision, interpolation arithmetic and float -> unorm rounding to the
