@@ -180,18 +180,23 @@ def predict_sequence_ycb(tracker, seq_dir, class_id, out_dir, start_frame=0, rei
 YCB_TEST_SEQUENCES = tuple(range(48, 60))   # predict.py:349 skips every video outside 0048..0059
 
 
-def get_results_ycb(tracker, ycb_dir, class_id, out_dir, seq_ids=YCB_TEST_SEQUENCES, max_frames=None, initialize_method="gt"):
+def get_results_ycb(tracker, ycb_dir, class_id, out_dir, seq_ids=YCB_TEST_SEQUENCES, max_frames=None, initialize_method="gt",
+                    lockstep=False):
     """The loop of predict.py:299-443 `getResultsYcb` (GT initialisation, no re-init, no video): every TEST
     sequence (48..59 by default, as predict.py:349; seq_ids=None takes every directory) under
     <ycb_dir>/data_organized/ that has pose_gt/<class_id>/ is tracked from its first frame and written as
     <out_dir>/seq<ID>/%07d.txt -- the layout eval_one_class / the reference's eval_ycb.py:95-96 parse
     (file index = frame id - 1).  initialize_method: 'gt' (what predict.py:301 hard-codes) | 'posecnn' (:362-373: the PoseCNN
     result of the keyframe 'SSSS/000001') | 'poserbpf' (:374-390): two of the three result columns the reference publishes
-    start from those.  Returns {seq_id: n_poses}."""
+    start from those.  Returns {seq_id: n_poses}.
+    lockstep = True (extension): the sequences of the class advance TOGETHER, frame index by frame index, through
+    ``tracker.on_track_batch`` (one se3tn_on_track_batch call per step for all sequences still running, in chunks of the tracker's
+    max_samples) instead of one after the other -- frames of one sequence stay serial, the sequences are independent; per sequence
+    the same arithmetic (up to 5 running sequences: the same bits as the serial loop).  The files written are the same."""
     if initialize_method not in ("gt", "posecnn", "poserbpf"):
         raise ValueError("initialize_method must be 'gt', 'posecnn' or 'poserbpf'")
     root = os.path.join(ycb_dir, "data_organized")
-    done = {}
+    seqs = []
     for seq_dir in sorted(glob.glob(os.path.join(root, "*"))):
         if not os.path.isdir(os.path.join(seq_dir, "pose_gt", str(class_id))):
             continue
@@ -209,16 +214,31 @@ def get_results_ycb(tracker, ycb_dir, class_id, out_dir, seq_ids=YCB_TEST_SEQUEN
             prev_pose = poserbpf_pose(ycb_dir, class_id, seq_id)
         else:
             prev_pose = np.loadtxt(gt_files[0])
-        pred = [prev_pose]
-        for i in range(1, n):
-            cur = tracker.on_track(prev_pose, read_rgb(rgb_files[i]), read_depth_mm(depth_files[i]))
-            prev_pose = cur.copy()
-            pred.append(cur)
-        sdir = os.path.join(out_dir, "seq%d" % seq_id)
+        seqs.append(dict(id=seq_id, rgb=rgb_files, depth=depth_files, n=n, prev=prev_pose, pred=[prev_pose]))
+    if lockstep:
+        cap = int(tracker.engine.max_batch)
+        for i in range(1, max([s["n"] for s in seqs] or [0])):
+            running = [s for s in seqs if i < s["n"]]
+            for c0 in range(0, len(running), cap):
+                chunk = running[c0:c0 + cap]
+                poses = tracker.on_track_batch([s["prev"] for s in chunk], [read_rgb(s["rgb"][i]) for s in chunk],
+                                               [read_depth_mm(s["depth"][i]) for s in chunk])
+                for s, p in zip(chunk, poses):
+                    s["prev"] = np.array(p, np.float64)
+                    s["pred"].append(s["prev"])
+    else:
+        for s in seqs:
+            for i in range(1, s["n"]):
+                cur = tracker.on_track(s["prev"], read_rgb(s["rgb"][i]), read_depth_mm(s["depth"][i]))
+                s["prev"] = cur.copy()
+                s["pred"].append(cur)
+    done = {}
+    for s in seqs:
+        sdir = os.path.join(out_dir, "seq%d" % s["id"])
         os.makedirs(sdir, exist_ok=True)
-        for i, p in enumerate(pred):
+        for i, p in enumerate(s["pred"]):
             np.savetxt(os.path.join(sdir, "%07d.txt" % i), p)
-        done[seq_id] = len(pred)
+        done[s["id"]] = len(s["pred"])
     return done
 
 

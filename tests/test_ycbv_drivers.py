@@ -106,6 +106,41 @@ def test_reinit_rule_and_file_layout_with_replayed_poses(golden, tree, seq, tmp_
     assert abs(ev["adi_auc"] - float(golden["eval_adi_auc"])) < 1e-9 and abs(ev["add_auc"] - float(golden["eval_add_auc"])) < 1e-9
 
 
+def test_lockstep_driver_feeds_every_sequence_its_own_track_and_writes_the_same_files(golden, tree, seq, tmp_path):
+    """get_results_ycb(lockstep=True): the sequences advance together through on_track_batch (CPU: a replaying stand-in that answers
+    per sequence with the reference run's poses).  Same files as the serial loop, every sequence fed its OWN previous pose, the batch
+    shrinking when the shorter sequence ends (0050 has 6 frames, 0048 has 9)."""
+    per_seq = {48: list(golden["res_poses"][1:9]), 50: list(golden["res_poses"][10:])}
+    fed_in = {48: list(golden["res_poses_in"][:8]), 50: list(golden["res_poses_in"][8:])}
+
+    class LockstepReplay:
+        object_cloud = None
+
+        class engine:
+            max_batch = 8
+
+        def __init__(self):
+            self.sizes, self.k = [], {48: 0, 50: 0}
+
+        def on_track_batch(self, poses, rgbs, depths):
+            self.sizes.append(len(poses))
+            out = []
+            for P in poses:
+                # which sequence is this?  the one whose next expected input pose matches
+                sid = next(s for s in (48, 50) if self.k[s] < len(fed_in[s]) and np.abs(np.asarray(P) - fed_in[s][self.k[s]]).max() < 1e-15)
+                out.append(per_seq[sid][self.k[sid]].copy())
+                self.k[sid] += 1
+            assert all(r.shape == YF.FRAME_HW + (3,) and r.dtype == np.uint8 for r in rgbs) and all(d.dtype == np.uint16 for d in depths)
+            return np.stack(out)
+
+    trk = LockstepReplay()
+    ldir = str(tmp_path / "lock")
+    assert seq.get_results_ycb(trk, tree, YF.CLASS_ID, ldir, lockstep=True) == {48: 9, 50: 6}
+    assert trk.sizes == [2] * 5 + [1] * 3 and trk.k == {48: 8, 50: 5}
+    for i, f in enumerate(golden["res_files"]):
+        assert np.array_equal(np.loadtxt(os.path.join(ldir, str(f))), golden["res_poses"][i])
+
+
 def test_posecnn_and_poserbpf_initialisation(golden, tree, seq, tmp_path):
     """the branches predict.py hard-codes away (initialize_method / init = 'gt'): same lookups as use_posecnn_res"""
     trk = ReplayTracker([np.eye(4)] * 20)
@@ -226,5 +261,11 @@ def test_dropin_ycbv_drivers_write_what_the_reference_drivers_write(golden, tree
     print("open loop (every on_track call of the reference's getResultsYcb run, its own pose fed): max |d pose| %.2e, 13 / 13 images A "
           "byte-identical" % d3)
     assert d3 < 1e-5
+    # lockstep (extension): both sequences advance together through Tracker.on_track_batch = se3tn_on_track_batch -- at two running
+    # sequences the batch-1-5 kernel family gives every pair the bits it has alone: the SAME files as the serial loop above
+    ldir = str(tmp_path / "res_lockstep")
+    assert se3.sequence.get_results_ycb(trk, tree, YF.CLASS_ID, ldir, lockstep=True) == done
+    for f in golden["res_files"]:
+        assert np.array_equal(np.loadtxt(os.path.join(ldir, str(f))), np.loadtxt(os.path.join(rdir, str(f)))), f
     assert np.abs(ev["adi_errs"] - golden["eval_adi_errs"]).max() < 2e-4 and np.abs(ev["add_errs"] - golden["eval_add_errs"]).max() < 2e-4
     assert abs(ev["adi_auc"] - float(golden["eval_adi_auc"])) < 5e-3 and abs(ev["add_auc"] - float(golden["eval_add_auc"])) < 5e-3
