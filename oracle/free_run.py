@@ -11,10 +11,15 @@ at, so errors cannot compound.  Here two closed loops run INDEPENDENTLY from the
     HIP track      P^h_{f+1} = next(P^h_f, Tracker.on_track(P^h_f, rgb_f, depth_f))      (renders its own image A on the GPU)
     oracle track   P^o_{f+1} = next(P^o_f, O.on_track(sd, P^o_f, rgb_f, depth_f, A^o_f))  (A^o_f = oracle/ss_fast.py render at P^o_f)
 
-with the feedback rule `next` of closed_loop._next_pose (rotation fully fed back, the network's own translation step carried
-on a seeded anchor trajectory; a random-init network has no reason to stay on the object).  Nothing of one side enters the
-other.  The oracle tracks run in worker processes (they cost ~0.1 s of CPU per frame; the HIP tracks 0.2 ms), which get the
-HIP track's images only to COUNT differing pixels.
+on two PROBLEMS (classes below), plus a CONTROL track per problem -- the oracle with channels-last network inputs: the same torch-CPU
+arithmetic in another summation order, i.e. how far the reference path separates from ITSELF:
+  * RandomInitProblem: the stand-in of oracle/closed_loop.py -- random-init weights with calibrated FC biases, frames that do not
+    contain the object, `next` = closed_loop._next_pose (rotation fully fed back, the network's own translation step carried on a
+    seeded anchor trajectory; a random-init network has no reason to stay on the object);
+  * SynthTrackProblem: oracle/synth_track.py -- an object that IS in the frames, ground-truth poses, stand-in weights TRAINED on it
+    (tests/golden/synth_tracker*.npz, one per normaliser regime), `next` = the identity: predict.py:416-420 unmodified.
+Nothing of one side enters the other.  The oracle tracks run in worker processes (they cost ~0.06-0.1 s of CPU per frame; the HIP
+tracks 0.2 ms), which get the HIP track's images only to COUNT differing pixels.
 
 What is reported per (regime, seed) track pair, over `frames` frames:
   * first frame whose integer bbox differs, number of frames with a differing bbox (the only discrete decisions on the
@@ -27,9 +32,10 @@ What is reported per (regime, seed) track pair, over `frames` frames:
     ADD-S AUC the HIP track would score if the oracle track were the ground truth (eval_ycb.py:45-64; 100 = identical).
 
 A random-init network is NOT a tracker: nothing pulls a perturbed pose back (a trained se(3)-TrackNet regresses the residual
-to the observed frame, so a 1e-6 perturbation of the pose is corrected by the next frame's estimate).  The figures below are
-therefore an upper bound on what rounding differences can do to a track of this length: they measure the open-loop
-sensitivity of the pose -> image A -> network -> pose map, accumulated over the run, with no restoring force."""
+to the observed frame, so a perturbation of the pose is corrected by the next frame's estimate).  The random-init figures are
+therefore an upper bound on what rounding differences can do to a track of this length -- the open-loop sensitivity of the
+pose -> image A -> network -> pose map with no restoring force -- and the trained-weights figures are the ones that say what
+"the same track" means (measured: DESIGN.md section 4, profiles/r06_free_run.json)."""
 import os
 import tempfile
 import time
