@@ -259,6 +259,34 @@ def test_on_track_batch_one_call_equals_the_stepwise_path(se3, n):
     assert np.abs(one - got[:len(one)]).max() < 1e-6
 
 
+def test_on_track_refuses_poses_that_have_no_crop_window(se3):
+    """se3tn_on_track / se3tn_on_track_batch reject a pose at or behind the camera plane, a non-finite pose and a
+    non-finite projection BEFORE the float -> int32 cast of compute_bbox's corners (undefined behaviour in C++), with an error code
+    and text -- and the context keeps working afterwards."""
+    sd = O.make_state_dict(0, head_gain=0.01)
+    mean, std = Fx.mean_std(0)
+    trk = se3.Tracker(dict(Fx.DATASET_INFO, object_width=150.0), mean, std, {"state_dict": sd}, max_samples=3)
+    trk.renderer = se3.HipRenderer(trk.engine, Fx.icosphere(2, 0.05, 1))
+    rgb, depth = Fx.synthetic_frame(71)
+    good = Fx.pose(3, (0.0, 0.0, 0.8))
+    want = trk.on_track(good, rgb, depth)
+    bad = []
+    for z in (0.0, -0.5, float("nan"), float("inf"), 1e-12):
+        P = good.copy(); P[2, 3] = z
+        bad.append(P)
+    P = good.copy(); P[0, 3] = float("nan")
+    bad.append(P)
+    for P in bad:
+        with pytest.raises(se3._lib.Se3tnError, match="camera|window"):
+            trk.on_track(P, rgb, depth)
+        with pytest.raises(se3._lib.Se3tnError, match="camera|window"):
+            trk.on_track_batch([good, P, good], [rgb] * 3, [depth] * 3)
+    assert np.array_equal(trk.on_track(good, rgb, depth), want)                         # the context is intact
+    assert np.array_equal(trk.on_track_batch([good] * 3, [rgb] * 3, [depth] * 3)[1], want)
+    with pytest.raises(ValueError):                                                     # frames of one call have one size
+        trk.on_track_batch([good, good], [rgb, rgb[:100]], [depth, depth[:100]])
+
+
 def test_hipgraph_replay_matches_eager(se3):
     """se3tn_enable_graphs: the captured se3tn_infer replays bit-identically, tracks argument changes
     (new pointers -> new capture) and content changes (same buffers, new data)."""
